@@ -1,0 +1,280 @@
+/* rt_hip.h -- C ABI of the MI355X (gfx950) render library `librt_hip.so`.
+ *
+ * This is the drop-in boundary for ONE path of rmehri01/raytracer: the
+ * per-pixel render loop
+ *     Camera::render -> ray_for_pixel -> World::color_at -> intersections ->
+ *     prepare_computations -> shade_hit -> is_shadowed / reflected_color /
+ *     refracted_color                       (reference: src/raytracer/camera.rs:51-80,
+ *                                             src/raytracer/world.rs:32-127)
+ * The reference has no FFI today; these are the entry points its
+ * `Camera::render` / `World::color_at` would bind after a host-side
+ * scene-flattening pass (INTEGRATION.md shows the Rust `extern "C"` block).
+ *
+ * Conventions
+ *   - plain pointers and sizes, no C++/torch types; every table is a flat array
+ *     of fixed-size records described below (row-major matrices, f64 maths);
+ *   - caller owns all host buffers for the duration of a call; the library owns
+ *     all device memory it allocates (scene tables) until *_destroy;
+ *   - return value: 0 = RT_OK, negative = error (rt_hip_strerror); nothing
+ *     unwinds across the boundary.  The reference panics/aborts instead
+ *     (Cargo.toml:8 `panic = "abort"`); a Rust wrapper turns non-zero into panic!;
+ *   - calls are blocking unless a stream argument says otherwise; the library is
+ *     not re-entrant per device (serialise calls that share a scene).
+ *   - there is NO CPU fallback: without a HIP device every compute entry point
+ *     returns RT_ERR_NO_DEVICE.
+ */
+#ifndef RT_HIP_H
+#define RT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes ------------------------------------------------------- */
+enum {
+    RT_OK = 0,
+    RT_ERR_NO_DEVICE = -1,     /* no HIP device / hipInit failed                    */
+    RT_ERR_HIP = -2,           /* a HIP runtime call failed (see rt_hip_last_hip_error) */
+    RT_ERR_INVALID_SCENE = -3, /* malformed tables (bad index, bad kind, cycle ...)  */
+    RT_ERR_NEST_TOO_DEEP = -4, /* compound nesting deeper than RT_MAX_NEST           */
+    RT_ERR_LIST_BOUND = -5,    /* a CSG subtree can yield more hits than RT_LIST_CAP */
+    RT_ERR_LIST_OVERFLOW = -6, /* run time: per-lane hit list overflowed (containers pass) */
+    RT_ERR_NAN_T = -7,         /* run time: a NaN intersection distance was dropped
+                                  (the reference would panic: intersection.rs:119)   */
+    RT_ERR_INVALID_ARG = -8,
+    RT_ERR_DEPTH = -9          /* recursion budget above RT_MAX_DEPTH                */
+};
+
+#define RT_MAX_NEST 8    /* max compound (group/CSG) nesting above a primitive      */
+#define RT_LIST_CAP 96   /* per-lane sorted-hit list capacity (entries)             */
+#define RT_MAX_DEPTH 8   /* max `remaining_recursions` (reference uses 5: camera.rs:59) */
+
+/* ---- shape kinds (reference: primitive.rs:237-266, compound.rs:121-131) --- */
+enum {
+    RT_SPHERE = 0,
+    RT_PLANE = 1,
+    RT_CUBE = 2,
+    RT_CYLINDER = 3,
+    RT_CONE = 4,
+    RT_TRIANGLE = 5,
+    RT_SMOOTH_TRIANGLE = 6,
+    RT_GROUP = 7,
+    RT_CSG = 8
+};
+/* flags, stored in RtShape.kind_flags bits 8.. */
+#define RT_FLAG_HAS_SHADOW (1u << 8)   /* primitive.rs:20,105                      */
+#define RT_FLAG_CLOSED (1u << 9)       /* Conic.closed, primitive.rs:457           */
+#define RT_FLAG_CSG_OP_SHIFT 10        /* 2 bits: 0 union, 1 intersection, 2 difference (compound.rs:135-139) */
+#define RT_KIND(kf) ((kf)&0xffu)
+
+/* ---- pattern node kinds (reference: pattern.rs:95-101,137-144) ------------ */
+enum {
+    RT_PAT_SOLID = 0,
+    RT_PAT_PERTURB = 1,
+    RT_PAT_BLEND = 2,
+    RT_PAT_STRIPE = 3,
+    RT_PAT_GRADIENT = 4,
+    RT_PAT_RADIAL_GRADIENT = 5,
+    RT_PAT_RING = 6,
+    RT_PAT_CHECKER = 7,
+    RT_PAT_TEST = 8 /* colour = point coordinates (pattern.rs:65-68,131), KATs only */
+};
+
+/* One record per shape (primitives AND compounds), 128 bytes = one L2 line.
+ * The table is the scene forest in depth-first pre-order: the subtree of shape
+ * i is the index range [i, skip), its first child is i+1, the next sibling of a
+ * child c is c.skip.  (reference types: shape.rs:38-43 Properties,
+ * primitive.rs:18-22, compound.rs:11-14)                                       */
+typedef struct RtShape {
+    double inv[12];      /* rows 0..2 of Properties.inverse_transform (row 3 is never read:
+                            matrix.rs:286-308 use rows 0..2 only)                   */
+    uint32_t kind_flags; /* RT_KIND in bits 0..7, RT_FLAG_* above                   */
+    int32_t parent;      /* enclosing compound, -1 at world level                   */
+    uint32_t skip;       /* first index after this subtree                          */
+    uint32_t material;   /* primitives: index into materials (compounds: ignored, Q8) */
+    uint32_t param;      /* cylinder/cone: conic index; (smooth)triangle: triangle index;
+                            group: group index; csg: csg index                      */
+    uint32_t depth;      /* number of enclosing compounds                           */
+    uint32_t pad[2];
+} RtShape;
+
+/* Conic limits (primitive.rs:454-458); closed flag lives in kind_flags. */
+typedef struct RtConic {
+    double minimum, maximum;
+} RtConic;
+
+/* Triangle data (primitive.rs:395-409, 253-265). e1 = p2-p1, e2 = p3-p1 are
+ * computed by the host exactly as Triangular::new does.  Flat triangles store
+ * their cached normal in n1 (n2,n3 unused). */
+typedef struct RtTriangle {
+    double p1[3], e1[3], e2[3];
+    double n1[3], n2[3], n3[3];
+} RtTriangle;
+
+/* Group: the box the reference tests per ray (compound.rs:93-95), i.e.
+ * Properties.bounds AFTER `bounds.transform(&self.transform)`, precomputed once
+ * on the host with the reference's own arithmetic (bounds.rs:19-35, Q5).
+ * bvh_root/bvh_count describe an optional acceleration structure over the
+ * group's direct children (acceleration only, never changes results). */
+typedef struct RtGroup {
+    double bmin[3], bmax[3];
+    int32_t bvh_root;  /* index into bvh nodes, -1 = none (linear scan of children) */
+    uint32_t n_children;
+} RtGroup;
+
+/* CSG node (compound.rs:126-130).  lhit[lhit_offset + (p - self - 1)] is 1 when
+ * `left.includes(shape p)` holds for primitive p of this subtree (structural
+ * equality, shape.rs:18-23, Q7), precomputed on the host. */
+typedef struct RtCsg {
+    uint32_t op; /* 0 union, 1 intersection, 2 difference */
+    uint32_t lhit_offset;
+} RtCsg;
+
+/* Material (material.rs:6-16), 12 doubles. */
+typedef struct RtMaterial {
+    double color[3];
+    double ambient, diffuse, specular, shininess;
+    double reflective, transparency, refractive_index;
+    int32_t pattern; /* root pattern node, -1 = none */
+    int32_t pad;
+    double pad2;
+} RtMaterial;
+
+/* Pattern tree node (pattern.rs:14-18,95-101).  Children by index. */
+typedef struct RtPattern {
+    double inv[12];  /* rows 0..2 of Pattern.inverse_transform */
+    double color[3]; /* RT_PAT_SOLID                           */
+    uint32_t kind;
+    int32_t a; /* mixture: first child; perturb: the child */
+    int32_t b; /* mixture: second child                    */
+    uint32_t pad;
+} RtPattern;
+
+/* Point light (point_light.rs:5-8). */
+typedef struct RtLight {
+    double position[3];
+    double intensity[3];
+} RtLight;
+
+/* Optional acceleration node over the direct children of one group (or over
+ * the world's top-level shapes).  Stackless "skip link" layout: visit node i;
+ * on box hit go to i+1, on miss go to `miss`.  Leaves name one child shape.
+ * Boxes are padded outward so that no child the reference would hit is culled;
+ * every accepted child is then tested with the reference's own arithmetic. */
+typedef struct RtBvhNode {
+    double bmin[3], bmax[3];
+    int32_t miss;  /* next node when the box is missed (or after a leaf); -1 = end */
+    int32_t shape; /* leaf: shape index, inner: -1 */
+} RtBvhNode;
+
+typedef struct RtSceneDesc {
+    uint32_t n_shapes;
+    const RtShape* shapes;
+    uint32_t n_conics;
+    const RtConic* conics;
+    uint32_t n_triangles;
+    const RtTriangle* triangles;
+    uint32_t n_groups;
+    const RtGroup* groups;
+    uint32_t n_csgs;
+    const RtCsg* csgs;
+    uint32_t n_lhit;
+    const uint8_t* lhit;
+    uint32_t n_materials;
+    const RtMaterial* materials;
+    uint32_t n_patterns;
+    const RtPattern* patterns;
+    uint32_t n_lights;
+    const RtLight* lights;
+    uint32_t n_bvh_nodes;
+    const RtBvhNode* bvh_nodes;
+    int32_t world_bvh_root; /* acceleration over top-level shapes, -1 = none */
+    uint32_t reserved;
+} RtSceneDesc;
+
+/* Camera (camera.rs:13-21): everything Camera::new / with_transform cached. */
+typedef struct RtCameraDesc {
+    uint32_t hsize, vsize;
+    double half_width, half_height, pixel_size;
+    double inv[16]; /* inverse_transform, row-major, all 4 rows */
+} RtCameraDesc;
+
+/* Event counters of one render (stats launches only).  Used for the FLOP
+ * budget of SURVEY.md 8(d) and cross-checked against the CPU oracle. */
+typedef struct RtStats {
+    uint64_t rays_primary, rays_shadow, rays_reflect, rays_refract;
+    uint64_t prim_tests[7];   /* by RT_SPHERE..RT_SMOOTH_TRIANGLE */
+    uint64_t ray_transforms;  /* ray -> object space transforms (ray.rs:19-24)  */
+    uint64_t group_gates;     /* semantic AABB tests (bounds.rs:53-77)          */
+    uint64_t bvh_box_tests;   /* acceleration-structure box tests               */
+    uint64_t hits_shaded;     /* prepare_computations + shade_hit evaluations   */
+    uint64_t normal_levels;   /* matrix levels walked in normal_at (both ways)  */
+    uint64_t lightings;       /* Primitive::lighting evaluations                */
+    uint64_t pow_calls;       /* powf in specular                               */
+    uint64_t pattern_nodes;   /* pattern nodes evaluated                        */
+    uint64_t container_passes;/* n1/n2 passes (second traversal)                */
+    uint64_t list_entries;    /* hits materialised into per-lane lists          */
+    uint64_t schlicks;
+    uint64_t status_flags;    /* OR of (1<<-err) run-time conditions            */
+    double kernel_ms;         /* device time of the launch (hipEvent)           */
+} RtStats;
+
+typedef struct RtScene RtScene; /* opaque: device-resident scene tables */
+
+/* Select `device` (hipSetDevice) and initialise the library for it.
+ * Replaces: nothing in the reference (process start).  Idempotent. */
+int rt_hip_init(int device);
+void rt_hip_shutdown(void);
+const char* rt_hip_strerror(int code);
+/* Text of the last HIP runtime error seen by this thread ("" if none). */
+const char* rt_hip_last_hip_error(void);
+
+/* Validate the tables and copy them to the current device.
+ * Replaces: the (implicit) borrow of `&World` by Camera::render (camera.rs:51). */
+int rt_hip_scene_create(const RtSceneDesc* desc, RtScene** out);
+void rt_hip_scene_destroy(RtScene* scene);
+
+/* Drop-in for `Camera::render(&self, world) -> Canvas` (camera.rs:51-66):
+ * renders hsize*vsize pixels with recursion budget `depth` (reference: 5,
+ * camera.rs:59) into the caller's HOST buffer out_rgb[vsize*hsize*3]
+ * (row-major, index = (y*hsize + x)*3, canvas.rs:30-38).  `stats` may be NULL. */
+int rt_hip_render(const RtSceneDesc* desc, const RtCameraDesc* cam, uint32_t depth, double* out_rgb,
+                  RtStats* stats);
+
+/* Same path with everything resident: renders a subset of image rows of a
+ * device-resident scene into DEVICE memory, asynchronously on `hip_stream`
+ * (a hipStream_t, NULL = default stream).  Local row k (0 <= k < n_local_rows)
+ * is image row ((k / band_rows) * n_parts + part) * band_rows + k % band_rows;
+ * rows >= vsize are skipped.  part=0,n_parts=1 renders rows [0,n_local_rows).
+ * d_out_rgb holds n_local_rows*hsize*3 doubles, local-row-major.
+ * Row tiles are how the path shards across GPUs (camera.rs:52-54 treats rows as
+ * independent rayon tasks).  If `d_stats` (device pointer to one RtStats,
+ * zeroed by the caller) is non-NULL the counting variant of the kernel runs. */
+int rt_hip_render_rows(const RtScene* scene, const RtCameraDesc* cam, uint32_t depth, uint32_t part,
+                       uint32_t n_parts, uint32_t band_rows, uint32_t n_local_rows,
+                       double* d_out_rgb, void* hip_stream, RtStats* d_stats);
+
+/* Drop-in for `World::color_at(&self, ray, remaining) -> Color` (world.rs:32-43)
+ * over a batch: rays[n*6] = origin xyz, direction xyz (HOST), out_rgb[n*3] (HOST). */
+int rt_hip_color_at(const RtScene* scene, const double* rays, uint32_t n, uint32_t depth,
+                    double* out_rgb);
+
+/* Debug/KAT probe of the first stage of color_at for a batch of rays (HOST
+ * buffers): out[n*16] = { hit(0/1), t, shape index, n1, n2, inside(0/1),
+ * point xyz(over_point), normal xyz, reflect xyz, is_shadowed(light 0) }.
+ * Mirrors what the reference unit tests inspect through Computations
+ * (intersection.rs:162-176). */
+int rt_hip_probe(const RtScene* scene, const double* rays, uint32_t n, double* out);
+
+/* Device-side 8-bit quantisation of a framebuffer, the rule of
+ * Canvas::scale_to_ppm_data (canvas.rs:85-90): clamp(c*255,0,255).round() as u8,
+ * NaN -> 0.  d_rgb and d_out are DEVICE pointers, n_values = pixels*3. */
+int rt_hip_quantize(const double* d_rgb, uint64_t n_values, uint8_t* d_out, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_HIP_H */

@@ -1,0 +1,1323 @@
+// rt_oracle.cpp -- CPU ORACLE.  TEST INFRASTRUCTURE ONLY.
+//
+// A literal C++17 restatement of the per-pixel render path of rmehri01/raytracer
+// (Camera::render -> World::color_at -> intersections -> prepare_computations ->
+// shade_hit -> is_shadowed / reflected_color / refracted_color), used as the
+// checker for the HIP kernels.  Only tests/, __graft_entry__.smoke() and the
+// cpu_baseline leg of bench.py may load this library; nothing in the product
+// (raytracer_amd/, include/) links, calls or falls back to it.
+//
+// It is deliberately NOT a fast ray tracer: it keeps the reference's object
+// tree, its per-ray sorted hit sets, its brute-force traversal and its
+// recursion, so that every function can be read against the file:line it
+// follows.  It shares no code with the product: matrices are inverted here,
+// bounds folded here, CSG membership decided here, independently.
+//
+// Pinning: byte-exact against images/ppm/shading.ppm and pixel
+// parity against the nine 2048x1080 golden renders (tests/golden/*.png), plus the
+// reference's unit-test known answers (tests/test_oracle_kat.py).
+// NOT pinned: the Perturb pattern.  The reference calls noise::SuperSimplex
+// (crate `noise` 0.7.0, Cargo.lock:275-283), which is absent from
+// /root/reference; `perturb_noise` below is an in-repo Perlin "improved noise"
+// standing in for it => Perturb is "parity unpinned" at source level.
+//
+// Arithmetic: IEEE binary64, one rounding per written operation.  Build with
+// -O2 -ffp-contract=off -fno-fast-math (oracle/Makefile).
+//
+// Rust std / `approx` semantics restated here:
+//   * BTreeSet::from_iter  = stable sort by Ord (exact t) + drop element i when
+//     it is PartialEq-equal to element i+1 (DedupSortedIter)  -> `collect_set`
+//   * BTreeSet::append     = sorted merge, on an exact-t tie the element of the
+//     appended set survives (MergeIter)                        -> `append_set`
+//   * Intersection ==      = ulps_eq(t, eps 1e-5, 4 ulps)       -> `hit_eq`
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <string>
+#include <vector>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace {
+
+constexpr double EPSILON = 1e-4;  // Point/Vector::default_epsilon, point.rs:69-71, vector.rs:103-105
+constexpr double INF = std::numeric_limits<double>::infinity();
+
+// ------------------------------------------------------------ core types ---
+struct V3 {  // Point, Vector and Color all carry three f64 (point.rs:8, vector.rs:8, color.rs:6)
+    double x, y, z;
+};
+inline V3 v3(double x, double y, double z) { return V3{x, y, z}; }
+inline V3 add(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+inline V3 sub(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+inline V3 mul(V3 a, double s) { return v3(a.x * s, a.y * s, a.z * s); }
+inline V3 had(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }  // color.rs:72-82
+inline V3 neg(V3 a) { return v3(-a.x, -a.y, -a.z); }
+inline double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }  // vector.rs:29-31
+inline V3 cross(V3 a, V3 b) {                                                // vector.rs:33-39
+    return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+inline double magnitude(V3 a) { return std::sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }  // vector.rs:25-27
+inline V3 normalize(V3 a) {  // vector.rs:19-23
+    const double m = magnitude(a);
+    return v3(a.x / m, a.y / m, a.z / m);
+}
+inline V3 reflect(V3 v, V3 n) {  // vector.rs:41-43: v - ((n*2.0) * (v.n))
+    return sub(v, mul(mul(n, 2.0), dot(v, n)));
+}
+
+inline bool abs_diff_eq(double a, double b, double eps) { return std::fabs(a - b) <= eps; }
+inline bool v3_eq(V3 a, V3 b) {  // 1e-4 on each coordinate
+    return abs_diff_eq(a.x, b.x, 1e-4) && abs_diff_eq(a.y, b.y, 1e-4) && abs_diff_eq(a.z, b.z, 1e-4);
+}
+// approx 0.5.1 ulps_eq for f64
+inline bool ulps_eq(double a, double b, double eps, uint64_t max_ulps) {
+    if (std::fabs(a - b) <= eps) return true;
+    if (std::isnan(a) || std::isnan(b)) return false;
+    if (std::signbit(a) != std::signbit(b)) return false;
+    uint64_t ia, ib;
+    std::memcpy(&ia, &a, 8);
+    std::memcpy(&ib, &b, 8);
+    return (ia <= ib ? ib - ia : ia - ib) <= max_ulps;
+}
+
+struct Mat4 {
+    double m[4][4];
+};
+Mat4 mat_identity() {
+    Mat4 r;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) r.m[i][j] = (i == j) ? 1.0 : 0.0;
+    return r;
+}
+Mat4 mat_transpose(const Mat4& a) {  // matrix.rs:25-35
+    Mat4 r;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) r.m[i][j] = a.m[j][i];
+    return r;
+}
+Mat4 mat_mul(const Mat4& a, const Mat4& b) {  // matrix.rs:268-284 (i,k,j)
+    Mat4 r;
+    std::memset(&r, 0, sizeof r);
+    for (int i = 0; i < 4; ++i)
+        for (int k = 0; k < 4; ++k)
+            for (int j = 0; j < 4; ++j) r.m[i][j] += a.m[i][k] * b.m[k][j];
+    return r;
+}
+inline V3 mat_point(const Mat4& a, V3 p) {  // matrix.rs:286-296
+    return v3(a.m[0][0] * p.x + a.m[0][1] * p.y + a.m[0][2] * p.z + a.m[0][3],
+              a.m[1][0] * p.x + a.m[1][1] * p.y + a.m[1][2] * p.z + a.m[1][3],
+              a.m[2][0] * p.x + a.m[2][1] * p.y + a.m[2][2] * p.z + a.m[2][3]);
+}
+inline V3 mat_vector(const Mat4& a, V3 v) {  // matrix.rs:298-308
+    return v3(a.m[0][0] * v.x + a.m[0][1] * v.y + a.m[0][2] * v.z,
+              a.m[1][0] * v.x + a.m[1][1] * v.y + a.m[1][2] * v.z,
+              a.m[2][0] * v.x + a.m[2][1] * v.y + a.m[2][2] * v.z);
+}
+// Generic N x N determinant machinery of matrix.rs:38-151, N = 2, 3, 4.
+double det2(const double a[2][2]) { return a[0][0] * a[1][1] - a[0][1] * a[1][0]; }
+double det3(const double a[3][3]) {
+    double det = 0.0;
+    for (int column = 0; column < 3; ++column) {
+        double s[2][2];
+        int i = 0;
+        for (int r = 0; r < 3; ++r) {
+            if (r == 0) continue;
+            int j = 0;
+            for (int c = 0; c < 3; ++c) {
+                if (c == column) continue;
+                s[i][j++] = a[r][c];
+            }
+            ++i;
+        }
+        const double sign = (column % 2 == 0) ? 1.0 : -1.0;
+        det += a[0][column] * (sign * det2(s));
+    }
+    return det;
+}
+double cofactor4(const Mat4& a, int row, int col) {
+    double s[3][3];
+    int i = 0;
+    for (int r = 0; r < 4; ++r) {
+        if (r == row) continue;
+        int j = 0;
+        for (int c = 0; c < 4; ++c) {
+            if (c == col) continue;
+            s[i][j++] = a.m[r][c];
+        }
+        ++i;
+    }
+    const double sign = ((row + col) % 2 == 0) ? 1.0 : -1.0;
+    return sign * det3(s);
+}
+double det4(const Mat4& a) {
+    double det = 0.0;
+    for (int column = 0; column < 4; ++column) det += a.m[0][column] * cofactor4(a, 0, column);
+    return det;
+}
+bool mat_inverse(const Mat4& a, Mat4& out) {  // matrix.rs:92-106
+    const double determinant = det4(a);
+    if (determinant == 0.0) return false;  // the reference asserts
+    for (int row = 0; row < 4; ++row)
+        for (int col = 0; col < 4; ++col) out.m[col][row] = cofactor4(a, row, col) / determinant;
+    return true;
+}
+bool mat_eq(const Mat4& a, const Mat4& b) {  // matrix.rs:247-266 (1e-5)
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j)
+            if (!abs_diff_eq(a.m[i][j], b.m[i][j], 1e-5)) return false;
+    return true;
+}
+
+struct Ray {  // ray.rs:5-24
+    V3 origin, direction;
+};
+inline V3 ray_position(const Ray& r, double t) { return add(r.origin, mul(r.direction, t)); }
+inline Ray ray_transform(const Ray& r, const Mat4& m) { return Ray{mat_point(m, r.origin), mat_vector(m, r.direction)}; }
+
+// ---------------------------------------------------------------- patterns ---
+enum PatKind { P_SOLID = 0, P_PERTURB, P_BLEND, P_STRIPE, P_GRADIENT, P_RADIAL, P_RING, P_CHECKER, P_TEST };
+
+struct Pattern {  // pattern.rs:13-18
+    int kind = P_SOLID;
+    Mat4 transform = mat_identity(), inverse = mat_identity();
+    V3 color{0, 0, 0};
+    std::unique_ptr<Pattern> a, b;
+};
+
+// Stand-in for noise::SuperSimplex (see header): Ken Perlin's 2002 "improved
+// noise" with his reference permutation.  The HIP kernel carries the same
+// table and the same operation order.
+const uint8_t PERLIN_PERM[256] = {
+    151, 160, 137, 91,  90,  15,  131, 13,  201, 95,  96,  53,  194, 233, 7,   225, 140, 36,  103, 30,  69,  142,
+    8,   99,  37,  240, 21,  10,  23,  190, 6,   148, 247, 120, 234, 75,  0,   26,  197, 62,  94,  252, 219, 203,
+    117, 35,  11,  32,  57,  177, 33,  88,  237, 149, 56,  87,  174, 20,  125, 136, 171, 168, 68,  175, 74,  165,
+    71,  134, 139, 48,  27,  166, 77,  146, 158, 231, 83,  111, 229, 122, 60,  211, 133, 230, 220, 105, 92,  41,
+    55,  46,  245, 40,  244, 102, 143, 54,  65,  25,  63,  161, 1,   216, 80,  73,  209, 76,  132, 187, 208, 89,
+    18,  169, 200, 196, 135, 130, 116, 188, 159, 86,  164, 100, 109, 198, 173, 186, 3,   64,  52,  217, 226, 250,
+    124, 123, 5,   202, 38,  147, 118, 126, 255, 82,  85,  212, 207, 206, 59,  227, 47,  16,  58,  17,  182, 189,
+    28,  42,  223, 183, 170, 213, 119, 248, 152, 2,   44,  154, 163, 70,  221, 153, 101, 155, 167, 43,  172, 9,
+    129, 22,  39,  253, 19,  98,  108, 110, 79,  113, 224, 232, 178, 185, 112, 104, 218, 246, 97,  228, 251, 34,
+    242, 193, 238, 210, 144, 12,  191, 179, 162, 241, 81,  51,  145, 235, 249, 14,  239, 107, 49,  192, 214, 31,
+    181, 199, 106, 157, 184, 84,  204, 176, 115, 121, 50,  45,  127, 4,   150, 254, 138, 236, 205, 93,  222, 114,
+    67,  29,  24,  72,  243, 141, 128, 195, 78,  66,  215, 61,  156, 180};
+inline int perm(int i) { return PERLIN_PERM[i & 255]; }
+inline double fade(double t) { return t * t * t * (t * (t * 6.0 - 15.0) + 10.0); }
+inline double lerp(double t, double a, double b) { return a + t * (b - a); }
+inline double grad(int hash, double x, double y, double z) {
+    const int h = hash & 15;
+    const double u = h < 8 ? x : y;
+    const double v = h < 4 ? y : (h == 12 || h == 14 ? x : z);
+    return ((h & 1) == 0 ? u : -u) + ((h & 2) == 0 ? v : -v);
+}
+double perturb_noise(double x, double y, double z) {
+    const double fx = std::floor(x), fy = std::floor(y), fz = std::floor(z);
+    // wrap the lattice cell to 0..255 without overflowing an int for huge inputs
+    const int X = static_cast<int>(std::fmod(fx, 256.0) + 256.0) & 255;
+    const int Y = static_cast<int>(std::fmod(fy, 256.0) + 256.0) & 255;
+    const int Z = static_cast<int>(std::fmod(fz, 256.0) + 256.0) & 255;
+    x -= fx, y -= fy, z -= fz;
+    const double u = fade(x), v = fade(y), w = fade(z);
+    const int A = perm(X) + Y, AA = perm(A) + Z, AB = perm(A + 1) + Z;
+    const int B = perm(X + 1) + Y, BA = perm(B) + Z, BB = perm(B + 1) + Z;
+    return lerp(w,
+                lerp(v, lerp(u, grad(perm(AA), x, y, z), grad(perm(BA), x - 1.0, y, z)),
+                     lerp(u, grad(perm(AB), x, y - 1.0, z), grad(perm(BB), x - 1.0, y - 1.0, z))),
+                lerp(v, lerp(u, grad(perm(AA + 1), x, y, z - 1.0), grad(perm(BA + 1), x - 1.0, y, z - 1.0)),
+                     lerp(u, grad(perm(AB + 1), x, y - 1.0, z - 1.0), grad(perm(BB + 1), x - 1.0, y - 1.0, z - 1.0))));
+}
+
+// Rust `f64 as i32`: saturating, NaN -> 0.
+inline int32_t f64_as_i32(double v) {
+    if (std::isnan(v)) return 0;
+    if (v >= 2147483647.0) return INT32_MAX;
+    if (v <= -2147483648.0) return INT32_MIN;
+    return static_cast<int32_t>(v);
+}
+
+V3 pattern_at(const Pattern& p, V3 object_point);  // pattern.rs:87-91
+
+V3 kind_pattern_at(const Pattern& p, V3 pp) {  // pattern.rs:103-133, 146-199
+    switch (p.kind) {
+        case P_SOLID: return p.color;
+        case P_TEST: return pp;
+        case P_PERTURB: {
+            const double PERTURB_AMOUNT = 0.4;
+            const V3 q = v3(pp.x + perturb_noise(pp.x, pp.y, pp.z) * PERTURB_AMOUNT,
+                            pp.y + perturb_noise(pp.x, pp.y, pp.z + 1.0) * PERTURB_AMOUNT,
+                            pp.z + perturb_noise(pp.x, pp.y, pp.z + 2.0) * PERTURB_AMOUNT);
+            return pattern_at(*p.a, q);
+        }
+        default: break;
+    }
+    const V3 a = pattern_at(*p.a, pp), b = pattern_at(*p.b, pp);  // both children, always
+    switch (p.kind) {
+        case P_BLEND: return mul(add(a, b), 0.5);
+        case P_STRIPE: return (f64_as_i32(std::floor(pp.x)) % 2 == 0) ? a : b;
+        case P_GRADIENT: {
+            const V3 distance = sub(b, a);
+            const double fraction = pp.x - std::floor(pp.x);
+            return add(a, mul(distance, fraction));
+        }
+        case P_RADIAL: {
+            const double distance = magnitude(sub(pp, v3(0, 0, 0)));
+            const double fraction = distance - std::floor(distance);
+            return add(a, mul(sub(b, a), fraction));
+        }
+        case P_RING: {
+            const double distance = std::hypot(pp.x, pp.z);
+            return (f64_as_i32(std::floor(distance)) % 2 == 0) ? a : b;
+        }
+        case P_CHECKER: {
+            const double sum_floors = std::floor(pp.x) + std::floor(pp.y) + std::floor(pp.z);
+            return (f64_as_i32(sum_floors) % 2 == 0) ? a : b;
+        }
+    }
+    return v3(0, 0, 0);
+}
+V3 pattern_at(const Pattern& p, V3 object_point) { return kind_pattern_at(p, mat_point(p.inverse, object_point)); }
+
+bool pattern_eq(const Pattern& a, const Pattern& b) {  // derived PartialEq
+    if (!mat_eq(a.transform, b.transform) || !mat_eq(a.inverse, b.inverse) || a.kind != b.kind) return false;
+    switch (a.kind) {
+        case P_SOLID: return v3_eq(a.color, b.color);
+        case P_TEST: return true;
+        case P_PERTURB: return pattern_eq(*a.a, *b.a);
+        default: return pattern_eq(*a.a, *b.a) && pattern_eq(*a.b, *b.b);
+    }
+}
+
+// ----------------------------------------------------------------- material ---
+struct Material {  // material.rs:6-16
+    V3 color{1, 1, 1};
+    double ambient = 0.1, diffuse = 0.9, specular = 0.9, shininess = 200.0;
+    double reflective = 0.0, transparency = 0.0, refractive_index = 1.0;
+    std::unique_ptr<Pattern> pattern;
+};
+bool material_eq(const Material& a, const Material& b) {  // material.rs:47-59
+    if (!v3_eq(a.color, b.color)) return false;
+    if (!abs_diff_eq(a.ambient, b.ambient, 1e-5) || !abs_diff_eq(a.diffuse, b.diffuse, 1e-5) ||
+        !abs_diff_eq(a.specular, b.specular, 1e-5) || !abs_diff_eq(a.shininess, b.shininess, 1e-5) ||
+        !abs_diff_eq(a.reflective, b.reflective, 1e-5) || !abs_diff_eq(a.transparency, b.transparency, 1e-5) ||
+        !abs_diff_eq(a.refractive_index, b.refractive_index, 1e-5))
+        return false;
+    if (static_cast<bool>(a.pattern) != static_cast<bool>(b.pattern)) return false;
+    return !a.pattern || pattern_eq(*a.pattern, *b.pattern);
+}
+
+struct Light {  // point_light.rs:5-8
+    V3 position, intensity;
+};
+
+// ------------------------------------------------------------------- bounds ---
+struct Bounds {  // bounds.rs:8-11, default :80-87
+    V3 minimum{INF, INF, INF}, maximum{-INF, -INF, -INF};
+};
+void bounds_add_point(Bounds& b, V3 p) {  // bounds.rs:44-51 (f64::min/max == fmin/fmax)
+    b.minimum.x = std::fmin(b.minimum.x, p.x);
+    b.minimum.y = std::fmin(b.minimum.y, p.y);
+    b.minimum.z = std::fmin(b.minimum.z, p.z);
+    b.maximum.x = std::fmax(b.maximum.x, p.x);
+    b.maximum.y = std::fmax(b.maximum.y, p.y);
+    b.maximum.z = std::fmax(b.maximum.z, p.z);
+}
+void bounds_union(Bounds& b, const Bounds& o) {  // bounds.rs:38-41
+    bounds_add_point(b, o.minimum);
+    bounds_add_point(b, o.maximum);
+}
+void bounds_transform(Bounds& b, const Mat4& t) {  // bounds.rs:19-35
+    const V3 mn = b.minimum, mx = b.maximum;
+    const V3 corners[8] = {mn,
+                           v3(mn.x, mn.y, mx.z),
+                           v3(mn.x, mx.y, mn.z),
+                           v3(mn.x, mx.y, mx.z),
+                           v3(mx.x, mn.y, mn.z),
+                           v3(mx.x, mn.y, mx.z),
+                           v3(mx.x, mx.y, mn.z),
+                           mx};
+    for (const V3& c : corners) bounds_add_point(b, mat_point(t, c));
+}
+// primitive.rs:380-392
+inline void check_axis(double origin, double direction, double min, double max, double& t_min, double& t_max) {
+    const double t_min_numerator = min - origin;
+    const double t_max_numerator = max - origin;
+    const double a = t_min_numerator / direction;
+    const double b = t_max_numerator / direction;
+    if (a > b) {
+        t_min = b, t_max = a;
+    } else {
+        t_min = a, t_max = b;
+    }
+}
+bool bounds_intersects(const Bounds& b, const Ray& ray) {  // bounds.rs:53-77
+    double x0, x1, y0, y1, z0, z1;
+    check_axis(ray.origin.x, ray.direction.x, b.minimum.x, b.maximum.x, x0, x1);
+    check_axis(ray.origin.y, ray.direction.y, b.minimum.y, b.maximum.y, y0, y1);
+    check_axis(ray.origin.z, ray.direction.z, b.minimum.z, b.maximum.z, z0, z1);
+    const double t_min = std::fmax(std::fmax(x0, y0), z0);
+    const double t_max = std::fmin(std::fmin(x1, y1), z1);
+    return t_min <= t_max;
+}
+bool bounds_eq(const Bounds& a, const Bounds& b) { return v3_eq(a.minimum, b.minimum) && v3_eq(a.maximum, b.maximum); }
+
+// ------------------------------------------------------------------- shapes ---
+enum ShapeKind { K_SPHERE = 0, K_PLANE, K_CUBE, K_CYLINDER, K_CONE, K_TRIANGLE, K_SMOOTH_TRIANGLE, K_GROUP, K_CSG };
+enum CsgOp { OP_UNION = 0, OP_INTERSECTION = 1, OP_DIFFERENCE = 2 };
+
+struct Node {  // Primitive (primitive.rs:18-22) or Compound (compound.rs:11-14)
+    int kind = K_SPHERE;
+    int id = -1;  // depth-first pre-order index over the whole world
+    bool has_shadow = true;
+    Mat4 transform = mat_identity(), inverse = mat_identity();
+    Material material;
+    Bounds bounds;
+    // Conic (primitive.rs:454-458)
+    double minimum = -INF, maximum = INF;
+    bool closed = false;
+    // Triangular (primitive.rs:395-401) + normals
+    V3 p1{}, p2{}, p3{}, e1{}, e2{}, n1{}, n2{}, n3{};
+    // Compound
+    int op = OP_UNION;
+    std::vector<std::unique_ptr<Node>> children;  // csg: [left, right]
+    bool is_primitive() const { return kind < K_GROUP; }
+};
+
+// A trail of group inverse transforms, innermost first (im_rc::Vector with push_front,
+// compound.rs:88-89).
+struct Trail {
+    int n = 0;
+    const Mat4* m[32] = {};
+    Trail pushed_front(const Mat4* x) const {
+        Trail t;
+        t.n = n + 1;
+        if (t.n > 32) {
+            std::fprintf(stderr, "oracle: nesting deeper than 32\n");
+            std::abort();
+        }
+        t.m[0] = x;
+        for (int i = 0; i < n; ++i) t.m[i + 1] = m[i];
+        return t;
+    }
+};
+
+struct Intersection {  // intersection.rs:14-19
+    double t;
+    const Node* shape;
+    bool has_uv;
+    double u, v;
+    Trail trail;
+};
+using Intersections = std::vector<Intersection>;  // always sorted: stands for BTreeSet<Intersection>
+
+inline bool hit_eq(const Intersection& a, const Intersection& b) {  // intersection.rs:102-107
+    return ulps_eq(a.t, b.t, 1e-5, 4);
+}
+inline void require_not_nan(double t) {
+    if (std::isnan(t)) {  // intersection.rs:119 .expect("t is not NaN"); release profile aborts
+        std::fprintf(stderr, "oracle: t is not NaN\n");
+        std::abort();
+    }
+}
+// BTreeSet::from_iter (Q2)
+Intersections collect_set(Intersections v) {
+    if (v.empty()) return v;
+    for (const auto& i : v)
+        if (v.size() > 1) require_not_nan(i.t);
+    std::stable_sort(v.begin(), v.end(), [](const Intersection& a, const Intersection& b) { return a.t < b.t; });
+    Intersections out;
+    out.reserve(v.size());
+    for (size_t i = 0; i < v.size(); ++i) {
+        if (i + 1 < v.size() && hit_eq(v[i], v[i + 1])) continue;  // DedupSortedIter drops the earlier one
+        out.push_back(v[i]);
+    }
+    return out;
+}
+// BTreeSet::append (Q1)
+void append_set(Intersections& self, Intersections& other) {
+    if (other.empty()) return;
+    if (self.empty()) {
+        self.swap(other);
+        return;
+    }
+    Intersections out;
+    out.reserve(self.size() + other.size());
+    size_t i = 0, j = 0;
+    while (i < self.size() && j < other.size()) {
+        require_not_nan(self[i].t);
+        require_not_nan(other[j].t);
+        if (self[i].t < other[j].t) {
+            out.push_back(self[i++]);
+        } else if (self[i].t > other[j].t) {
+            out.push_back(other[j++]);
+        } else {  // equal keys: the pair from the right source
+            out.push_back(other[j++]);
+            ++i;
+        }
+    }
+    while (i < self.size()) out.push_back(self[i++]);
+    while (j < other.size()) out.push_back(other[j++]);
+    self.swap(out);
+    other.clear();
+}
+
+// ---- primitive intersection routines (primitive.rs:268-329, 416-440, 481-533) ---
+void sphere_intersect(const Ray& ray, std::vector<double>& ts) {
+    const V3 sphere_to_ray = sub(ray.origin, v3(0.0, 0.0, 0.0));
+    const double a = dot(ray.direction, ray.direction);
+    const double b = 2.0 * dot(sphere_to_ray, ray.direction);
+    const double c = dot(sphere_to_ray, sphere_to_ray) - 1.0;
+    const double discriminant = b * b - 4.0 * a * c;
+    if (discriminant < 0.0) return;
+    ts.push_back((-b - std::sqrt(discriminant)) / (2.0 * a));
+    ts.push_back((-b + std::sqrt(discriminant)) / (2.0 * a));
+}
+void plane_intersect(const Ray& ray, std::vector<double>& ts) {
+    if (std::fabs(ray.direction.y) < EPSILON) return;
+    ts.push_back(-ray.origin.y / ray.direction.y);
+}
+void cube_intersect(const Ray& ray, std::vector<double>& ts) {
+    double x0, x1, y0, y1, z0, z1;
+    check_axis(ray.origin.x, ray.direction.x, -1.0, 1.0, x0, x1);
+    check_axis(ray.origin.y, ray.direction.y, -1.0, 1.0, y0, y1);
+    check_axis(ray.origin.z, ray.direction.z, -1.0, 1.0, z0, z1);
+    const double t_min = std::fmax(std::fmax(x0, y0), z0);
+    const double t_max = std::fmin(std::fmin(x1, y1), z1);
+    if (t_min > t_max) return;
+    ts.push_back(t_min);
+    ts.push_back(t_max);
+}
+inline bool check_cap(const Ray& ray, double t, double radius) {  // primitive.rs:528-533
+    const double x = ray.origin.x + t * ray.direction.x;
+    const double z = ray.origin.z + t * ray.direction.z;
+    return (x * x + z * z) <= radius * radius;
+}
+void conic_intersect(const Node& s, const Ray& ray, double a, double b, double c, bool cone, std::vector<double>& xs) {
+    const double discriminant = b * b - 4.0 * a * c;  // primitive.rs:482
+    // intersect_caps, primitive.rs:510-526; radius_at = |_| 1.0 (cylinder) or f64::abs (cone)
+    if (s.closed && !abs_diff_eq(ray.direction.y, 0.0, EPSILON)) {
+        double t = (s.minimum - ray.origin.y) / ray.direction.y;
+        if (check_cap(ray, t, cone ? std::fabs(s.minimum) : 1.0)) xs.push_back(t);
+        t = (s.maximum - ray.origin.y) / ray.direction.y;
+        if (check_cap(ray, t, cone ? std::fabs(s.maximum) : 1.0)) xs.push_back(t);
+    }
+    if (discriminant >= 0.0) {
+        if (abs_diff_eq(a, 0.0, EPSILON)) {
+            if (!abs_diff_eq(b, 0.0, EPSILON)) xs.push_back(-c / (2.0 * b));
+        } else {
+            const double t0 = (-b - std::sqrt(discriminant)) / (2.0 * a);
+            const double t1 = (-b + std::sqrt(discriminant)) / (2.0 * a);
+            const double y0 = ray.origin.y + t0 * ray.direction.y;
+            if (s.minimum < y0 && y0 < s.maximum) xs.push_back(t0);
+            const double y1 = ray.origin.y + t1 * ray.direction.y;
+            if (s.minimum < y1 && y1 < s.maximum) xs.push_back(t1);
+        }
+    }
+}
+void cylinder_intersect(const Node& s, const Ray& ray, std::vector<double>& ts) {  // primitive.rs:314-320
+    const V3 &o = ray.origin, &d = ray.direction;
+    const double a = d.x * d.x + d.z * d.z;
+    const double b = 2.0 * o.x * d.x + 2.0 * o.z * d.z;
+    const double c = o.x * o.x + o.z * o.z - 1.0;
+    conic_intersect(s, ray, a, b, c, false, ts);
+}
+void cone_intersect(const Node& s, const Ray& ray, std::vector<double>& ts) {  // primitive.rs:322-329
+    const V3 &o = ray.origin, &d = ray.direction;
+    const double a = d.x * d.x - d.y * d.y + d.z * d.z;
+    const double b = 2.0 * o.x * d.x - 2.0 * o.y * d.y + 2.0 * o.z * d.z;
+    const double c = o.x * o.x - o.y * o.y + o.z * o.z;
+    conic_intersect(s, ray, a, b, c, true, ts);
+}
+void triangle_intersect_uv(const Node& s, const Ray& ray, std::vector<double>& ts, double& u, double& v) {
+    const V3 dir_cross_e2 = cross(ray.direction, s.e2);  // primitive.rs:416-440
+    const double det = dot(s.e1, dir_cross_e2);
+    const double f = 1.0 / det;
+    const V3 p1_to_origin = sub(ray.origin, s.p1);
+    u = f * dot(p1_to_origin, dir_cross_e2);
+    const V3 origin_cross_e1 = cross(p1_to_origin, s.e1);
+    v = f * dot(ray.direction, origin_cross_e1);
+    const bool u_in = (0.0 <= u && u <= 1.0);
+    if (abs_diff_eq(std::fabs(det), 0.0, EPSILON) || !u_in || v < 0.0 || (u + v) > 1.0) return;
+    ts.push_back(f * dot(s.e2, origin_cross_e1));
+}
+
+Intersections intersect(const Node& s, const Ray& ray, const Trail& trail);  // shape.rs:28-32
+
+Intersections primitive_local_intersect(const Node& s, const Ray& ray, const Trail& trail) {  // primitive.rs:210-233
+    std::vector<double> ts;
+    bool has_uv = false;
+    double u = 0.0, v = 0.0;
+    switch (s.kind) {
+        case K_SPHERE: sphere_intersect(ray, ts); break;
+        case K_PLANE: plane_intersect(ray, ts); break;
+        case K_CUBE: cube_intersect(ray, ts); break;
+        case K_CYLINDER: cylinder_intersect(s, ray, ts); break;
+        case K_CONE: cone_intersect(s, ray, ts); break;
+        case K_TRIANGLE: triangle_intersect_uv(s, ray, ts, u, v); break;
+        case K_SMOOTH_TRIANGLE:
+            triangle_intersect_uv(s, ray, ts, u, v);
+            has_uv = true;
+            break;
+    }
+    Intersections xs;
+    for (double t : ts) xs.push_back(Intersection{t, &s, has_uv, u, v, trail});
+    return collect_set(std::move(xs));
+}
+
+bool includes(const Node& shape, const Node& other);
+
+// derived PartialEq of Primitive (primitive.rs:17), used by Shape::includes (shape.rs:18-23)
+bool primitive_eq(const Node& a, const Node& b) {
+    if (!mat_eq(a.transform, b.transform) || !mat_eq(a.inverse, b.inverse)) return false;
+    if (!material_eq(a.material, b.material)) return false;
+    if (!bounds_eq(a.bounds, b.bounds)) return false;
+    if (a.has_shadow != b.has_shadow || a.kind != b.kind) return false;
+    switch (a.kind) {
+        case K_CYLINDER:
+        case K_CONE:
+            return abs_diff_eq(a.minimum, b.minimum, 1e-5) && abs_diff_eq(a.maximum, b.maximum, 1e-5) &&
+                   a.closed == b.closed;
+        case K_TRIANGLE:
+            return v3_eq(a.p1, b.p1) && v3_eq(a.p2, b.p2) && v3_eq(a.p3, b.p3) && v3_eq(a.e1, b.e1) &&
+                   v3_eq(a.e2, b.e2) && v3_eq(a.n1, b.n1);
+        case K_SMOOTH_TRIANGLE:
+            return v3_eq(a.p1, b.p1) && v3_eq(a.p2, b.p2) && v3_eq(a.p3, b.p3) && v3_eq(a.e1, b.e1) &&
+                   v3_eq(a.e2, b.e2) && v3_eq(a.n1, b.n1) && v3_eq(a.n2, b.n2) && v3_eq(a.n3, b.n3);
+        default: return true;
+    }
+}
+bool includes(const Node& shape, const Node& other) {  // shape.rs:18-23, compound.rs:64-69
+    if (shape.is_primitive()) return primitive_eq(shape, other);
+    for (const auto& c : shape.children)
+        if (includes(*c, other)) return true;
+    return false;
+}
+
+inline bool intersection_allowed(int op, bool l_hit, bool in_l, bool in_r) {  // compound.rs:175-181
+    switch (op) {
+        case OP_UNION: return (l_hit && !in_r) || (!l_hit && !in_l);
+        case OP_INTERSECTION: return (l_hit && in_r) || (!l_hit && in_l);
+        default: return (l_hit && !in_r) || (!l_hit && in_l);
+    }
+}
+Intersections filter_intersections(int op, const Node& left, const Intersections& xs) {  // compound.rs:142-168
+    bool in_l = false, in_r = false;
+    Intersections kept;
+    for (const Intersection& i : xs) {
+        const bool l_hit = includes(left, *i.shape);
+        const bool allowed = intersection_allowed(op, l_hit, in_l, in_r);
+        if (l_hit)
+            in_l = !in_l;
+        else
+            in_r = !in_r;
+        if (allowed) kept.push_back(i);
+    }
+    return collect_set(std::move(kept));  // `.collect()` into a BTreeSet again
+}
+
+Intersections compound_local_intersect(const Node& s, const Ray& ray, const Trail& trail) {  // compound.rs:87-117
+    const Trail new_trail = trail.pushed_front(&s.inverse);
+    if (s.kind == K_GROUP) {
+        Bounds bounds = s.bounds;
+        bounds_transform(bounds, s.transform);
+        if (!bounds_intersects(bounds, ray)) return {};
+        Intersections acc;
+        for (const auto& child : s.children) {
+            Intersections xs = intersect(*child, ray, new_trail);
+            append_set(acc, xs);
+        }
+        return acc;
+    }
+    Intersections left_intersections = intersect(*s.children[0], ray, new_trail);
+    Intersections right_intersections = intersect(*s.children[1], ray, new_trail);
+    append_set(left_intersections, right_intersections);
+    return filter_intersections(s.op, *s.children[0], left_intersections);
+}
+
+Intersections intersect(const Node& s, const Ray& ray, const Trail& trail) {
+    const Ray local_ray = ray_transform(ray, s.inverse);
+    return s.is_primitive() ? primitive_local_intersect(s, local_ray, trail)
+                            : compound_local_intersect(s, local_ray, trail);
+}
+
+// ---- normals (primitive.rs:153-192, 331-375, 469-479) ----------------------
+V3 world_to_object(const Node& s, V3 world_point, const Trail& trail) {
+    V3 p = world_point;
+    for (int i = trail.n - 1; i >= 0; --i) p = mat_point(*trail.m[i], p);  // .iter().rev(): outermost first
+    return mat_point(s.inverse, p);
+}
+V3 normal_to_world(const Node& s, V3 normal, const Trail& trail) {
+    V3 n = normalize(mat_vector(mat_transpose(s.inverse), normal));
+    for (int i = 0; i < trail.n; ++i) n = normalize(mat_vector(mat_transpose(*trail.m[i]), n));
+    return n;
+}
+V3 conic_normal_at(const Node& s, V3 p, double y) {
+    const double dist = p.x * p.x + p.z * p.z;
+    if (dist < 1.0 && p.y >= s.maximum - EPSILON) return v3(0.0, 1.0, 0.0);
+    if (dist < 1.0 && p.y <= s.minimum + EPSILON) return v3(0.0, -1.0, 0.0);
+    return v3(p.x, y, p.z);
+}
+V3 local_normal_at(const Node& s, V3 p, const Intersection& hit) {
+    switch (s.kind) {
+        case K_SPHERE: return sub(p, v3(0.0, 0.0, 0.0));
+        case K_PLANE: return v3(0.0, 1.0, 0.0);
+        case K_CUBE: {
+            const double max_c = std::fmax(std::fmax(std::fabs(p.x), std::fabs(p.y)), std::fabs(p.z));
+            if (abs_diff_eq(max_c, std::fabs(p.x), EPSILON)) return v3(p.x, 0.0, 0.0);
+            if (abs_diff_eq(max_c, std::fabs(p.y), EPSILON)) return v3(0.0, p.y, 0.0);
+            return v3(0.0, 0.0, p.z);
+        }
+        case K_CYLINDER: return conic_normal_at(s, p, 0.0);
+        case K_CONE: {
+            double y = std::hypot(p.x, p.z);
+            if (p.y > 0.0) y = -y;
+            return conic_normal_at(s, p, y);
+        }
+        case K_TRIANGLE: return s.n1;
+        case K_SMOOTH_TRIANGLE: {
+            if (!hit.has_uv) {
+                std::fprintf(stderr, "oracle: u and v must be set for smooth triangle\n");
+                std::abort();
+            }
+            return add(add(mul(s.n2, hit.u), mul(s.n3, hit.v)), mul(s.n1, 1.0 - hit.u - hit.v));
+        }
+    }
+    return v3(0, 0, 0);
+}
+V3 normal_at(const Node& s, V3 point, const Intersection& hit) {
+    const V3 local_point = world_to_object(s, point, hit.trail);
+    return normal_to_world(s, local_normal_at(s, local_point, hit), hit.trail);
+}
+
+// ---- lighting (primitive.rs:111-151) ----------------------------------------
+V3 lighting(const Node& s, V3 position, const Light& light, V3 eye_v, V3 normal_v, bool in_shadow, const Trail& trail) {
+    const Material& material = s.material;
+    V3 color = material.color;
+    if (material.pattern) color = pattern_at(*material.pattern, world_to_object(s, position, trail));  // pattern.rs:76-85
+    const V3 effective_color = had(color, light.intensity);
+    const V3 light_v = normalize(sub(light.position, position));
+    const V3 ambient = mul(effective_color, material.ambient);
+    V3 diffuse = v3(0, 0, 0), specular = v3(0, 0, 0);
+    const double light_dot_normal = dot(light_v, normal_v);
+    if (!(light_dot_normal < 0.0 || in_shadow)) {
+        diffuse = mul(mul(effective_color, material.diffuse), light_dot_normal);
+        const V3 reflect_v = reflect(neg(light_v), normal_v);
+        const double reflect_dot_eye = dot(reflect_v, eye_v);
+        if (!(reflect_dot_eye <= 0.0)) {
+            const double factor = std::pow(reflect_dot_eye, material.shininess);
+            specular = mul(mul(light.intensity, material.specular), factor);
+        }
+    }
+    return add(add(ambient, diffuse), specular);
+}
+
+// ---- computations (intersection.rs:45-99, 162-200) ---------------------------
+struct Computations {
+    const Node* shape;
+    Trail trail;
+    V3 point, over_point, under_point, eye_v, normal_v, reflect_v;
+    bool inside;
+    double n1, n2;
+};
+Computations prepare_computations(const Intersection& self, const Ray& ray, const Intersections& xs) {
+    std::vector<const Node*> containers;
+    bool has_n1 = false, has_n2 = false;
+    double n1 = 0.0, n2 = 0.0;
+    for (const Intersection& i : xs) {
+        const bool is_self = hit_eq(i, self);
+        if (is_self) {
+            has_n1 = !containers.empty();
+            if (has_n1) n1 = containers.back()->material.refractive_index;
+        }
+        auto pos = std::find(containers.begin(), containers.end(), i.shape);  // ptr::eq
+        if (pos != containers.end())
+            containers.erase(pos);
+        else
+            containers.push_back(i.shape);
+        if (is_self) {
+            has_n2 = !containers.empty();
+            if (has_n2) n2 = containers.back()->material.refractive_index;
+            break;
+        }
+    }
+    Computations c;
+    c.point = ray_position(ray, self.t);
+    c.eye_v = neg(ray.direction);
+    V3 normal_v = normal_at(*self.shape, c.point, self);
+    c.inside = dot(normal_v, c.eye_v) < 0.0;
+    if (c.inside) normal_v = neg(normal_v);
+    c.shape = self.shape;
+    c.trail = self.trail;
+    c.over_point = add(c.point, mul(normal_v, EPSILON));
+    c.under_point = sub(c.point, mul(normal_v, EPSILON));
+    c.normal_v = normal_v;
+    c.reflect_v = reflect(ray.direction, normal_v);
+    c.n1 = has_n1 ? n1 : 1.0;
+    c.n2 = has_n2 ? n2 : 1.0;
+    return c;
+}
+double schlick(const Computations& c) {  // intersection.rs:182-200
+    double cosv = dot(c.eye_v, c.normal_v);
+    if (c.n1 > c.n2) {
+        const double n = c.n1 / c.n2;
+        const double sin2_t = (n * n) * (1.0 - cosv * cosv);
+        if (sin2_t > 1.0) return 1.0;
+        cosv = std::sqrt(1.0 - sin2_t);
+    }
+    const double r = (c.n1 - c.n2) / (c.n1 + c.n2);
+    const double r0 = r * r;
+    const double x = 1.0 - cosv;
+    const double x2 = x * x;  // powi(5): x^2 -> x^4 -> x^4 * x (Q11)
+    const double x4 = x2 * x2;
+    return r0 + (1.0 - r0) * (x4 * x);
+}
+
+// -------------------------------------------------------------------- world ---
+struct RayCounts {
+    uint64_t primary = 0, shadow = 0, reflect = 0, refract = 0;
+};
+struct World {  // world.rs:18-21
+    std::vector<std::unique_ptr<Node>> shapes;
+    std::vector<Light> lights;
+    int n_nodes = 0;
+    std::vector<const Node*> by_id;
+};
+
+Intersections world_intersections(const World& w, const Ray& ray) {  // world.rs:45-53
+    const Trail trail{};
+    Intersections acc;
+    for (const auto& shape : w.shapes) {
+        Intersections xs = intersect(*shape, ray, trail);
+        append_set(acc, xs);
+    }
+    return acc;
+}
+const Intersection* find_hit(const Intersections& xs, bool shadow_only) {  // intersection.rs:154-158
+    for (const Intersection& i : xs)
+        if (i.t >= 0.0 && (!shadow_only || i.shape->has_shadow)) return &i;
+    return nullptr;
+}
+bool is_shadowed(const World& w, V3 point, V3 light_position, RayCounts* rc) {  // world.rs:85-96
+    const V3 v = sub(light_position, point);
+    const double distance = magnitude(v);
+    const V3 direction = normalize(v);
+    const Ray r{point, direction};
+    if (rc) ++rc->shadow;
+    const Intersections xs = world_intersections(w, r);
+    const Intersection* hit = find_hit(xs, true);
+    return hit != nullptr && hit->t < distance;
+}
+
+V3 color_at(const World& w, const Ray& ray, int remaining, RayCounts* rc);
+
+V3 shade_hit(const World& w, const Computations& comps, int remaining, RayCounts* rc) {  // world.rs:55-83
+    V3 surface = v3(0.0, 0.0, 0.0);  // Sum folds from BLACK, color.rs:42-46
+    for (const Light& light : w.lights) {
+        const bool shadowed = is_shadowed(w, comps.over_point, light.position, rc);
+        surface = add(surface, lighting(*comps.shape, comps.over_point, light, comps.eye_v, comps.normal_v, shadowed,
+                                        comps.trail));
+    }
+    const Material& material = comps.shape->material;
+    // reflected_color, world.rs:98-107
+    V3 reflected = v3(0.0, 0.0, 0.0);
+    if (!(material.reflective == 0.0 || remaining == 0)) {
+        const Ray reflect_ray{comps.over_point, comps.reflect_v};
+        if (rc) ++rc->reflect;
+        reflected = mul(color_at(w, reflect_ray, remaining - 1, rc), material.reflective);
+    }
+    // refracted_color, world.rs:109-127
+    V3 refracted = v3(0.0, 0.0, 0.0);
+    {
+        const double n_ratio = comps.n1 / comps.n2;
+        const double cos_i = dot(comps.eye_v, comps.normal_v);
+        const double sin2_t = (n_ratio * n_ratio) * (1.0 - cos_i * cos_i);
+        if (!(material.transparency == 0.0 || remaining == 0 || sin2_t > 1.0)) {
+            const double cos_t = std::sqrt(1.0 - sin2_t);
+            const V3 direction = sub(mul(comps.normal_v, n_ratio * cos_i - cos_t), mul(comps.eye_v, n_ratio));
+            const Ray refract_ray{comps.under_point, direction};
+            if (rc) ++rc->refract;
+            refracted = mul(color_at(w, refract_ray, remaining - 1, rc), material.transparency);
+        }
+    }
+    if (material.reflective > 0.0 && material.transparency > 0.0) {
+        const double reflectance = schlick(comps);
+        return add(add(surface, mul(reflected, reflectance)), mul(refracted, 1.0 - reflectance));
+    }
+    return add(add(surface, reflected), refracted);
+}
+
+V3 color_at(const World& w, const Ray& ray, int remaining, RayCounts* rc) {  // world.rs:32-43
+    const Intersections xs = world_intersections(w, ray);
+    const Intersection* hit = find_hit(xs, false);
+    if (!hit) return v3(0.0, 0.0, 0.0);
+    const Computations comps = prepare_computations(*hit, ray, xs);
+    return shade_hit(w, comps, remaining, rc);
+}
+
+// ------------------------------------------------------------------- camera ---
+struct Camera {  // camera.rs:13-43
+    int h_size, v_size;
+    Mat4 inverse;
+    double half_width, half_height, pixel_size;
+};
+bool camera_new(int h_size, int v_size, double fov, const double* transform16, int transform_set, Camera& c) {
+    const double half_view = std::tan(fov / 2.0);
+    const double aspect = static_cast<double>(h_size) / static_cast<double>(v_size);
+    if (aspect >= 1.0) {
+        c.half_width = half_view;
+        c.half_height = half_view / aspect;
+    } else {
+        c.half_width = half_view * aspect;
+        c.half_height = half_view;
+    }
+    c.h_size = h_size, c.v_size = v_size;
+    c.pixel_size = (c.half_width * 2.0) / static_cast<double>(h_size);
+    c.inverse = mat_identity();
+    if (transform_set) {
+        Mat4 t;
+        std::memcpy(t.m, transform16, sizeof t.m);
+        if (!mat_inverse(t, c.inverse)) return false;
+    }
+    return true;
+}
+Ray ray_for_pixel(const Camera& c, int px, int py) {  // camera.rs:68-80
+    const double x_offset = (static_cast<double>(px) + 0.5) * c.pixel_size;
+    const double y_offset = (static_cast<double>(py) + 0.5) * c.pixel_size;
+    const double world_x = c.half_width - x_offset;
+    const double world_y = c.half_height - y_offset;
+    const V3 pixel = mat_point(c.inverse, v3(world_x, world_y, -1.0));
+    const V3 origin = mat_point(c.inverse, v3(0.0, 0.0, 0.0));
+    return Ray{origin, normalize(sub(pixel, origin))};
+}
+
+// ----------------------------------------------------- description parser ---
+struct Reader {
+    const double* p;
+    size_t n, i = 0;
+    bool ok = true;
+    double next() {
+        if (i >= n) {
+            ok = false;
+            return 0.0;
+        }
+        return p[i++];
+    }
+    V3 v() {
+        const double x = next(), y = next(), z = next();
+        return v3(x, y, z);
+    }
+    Mat4 mat() {
+        Mat4 m;
+        for (int a = 0; a < 4; ++a)
+            for (int b = 0; b < 4; ++b) m.m[a][b] = next();
+        return m;
+    }
+};
+bool read_transform(Reader& r, Mat4& transform, Mat4& inverse) {
+    const bool set = r.next() != 0.0;
+    transform = r.mat();
+    inverse = mat_identity();
+    if (set) return mat_inverse(transform, inverse);  // shape.rs:63-67 / pattern.rs:70-74
+    return true;
+}
+std::unique_ptr<Pattern> read_pattern(Reader& r, int depth = 0) {
+    if (!r.ok || depth > 64) return nullptr;
+    auto p = std::make_unique<Pattern>();
+    p->kind = static_cast<int>(r.next());
+    if (!read_transform(r, p->transform, p->inverse)) {
+        r.ok = false;
+        return nullptr;
+    }
+    switch (p->kind) {
+        case P_SOLID: p->color = r.v(); break;
+        case P_TEST: break;
+        case P_PERTURB: p->a = read_pattern(r, depth + 1); break;
+        case P_BLEND: case P_STRIPE: case P_GRADIENT: case P_RADIAL: case P_RING: case P_CHECKER:
+            p->a = read_pattern(r, depth + 1);
+            p->b = read_pattern(r, depth + 1);
+            break;
+        default: r.ok = false;
+    }
+    return p;
+}
+void read_material(Reader& r, Material& m) {
+    m.color = r.v();
+    m.ambient = r.next(), m.diffuse = r.next(), m.specular = r.next(), m.shininess = r.next();
+    m.reflective = r.next(), m.transparency = r.next(), m.refractive_index = r.next();
+    if (r.next() != 0.0) m.pattern = read_pattern(r);
+}
+std::unique_ptr<Node> read_shape(Reader& r, World& w, int depth = 0) {
+    if (!r.ok || depth > 30) {
+        r.ok = false;
+        return nullptr;
+    }
+    auto s = std::make_unique<Node>();
+    s->kind = static_cast<int>(r.next());
+    s->id = w.n_nodes++;
+    w.by_id.push_back(s.get());
+    s->has_shadow = r.next() != 0.0;
+    if (!read_transform(r, s->transform, s->inverse)) {
+        r.ok = false;
+        return nullptr;
+    }
+    read_material(r, s->material);
+    switch (s->kind) {
+        case K_SPHERE:
+        case K_CUBE:  // primitive.rs:38-40
+            s->bounds = Bounds{v3(-1, -1, -1), v3(1, 1, 1)};
+            break;
+        case K_PLANE:  // primitive.rs:41-44
+            s->bounds = Bounds{v3(-INF, 0.0, -INF), v3(INF, 0.0, INF)};
+            break;
+        case K_CYLINDER:
+        case K_CONE:
+            s->minimum = r.next(), s->maximum = r.next(), s->closed = r.next() != 0.0;
+            s->bounds = Bounds{v3(-1.0, s->minimum, -1.0), v3(1.0, s->maximum, 1.0)};  // primitive.rs:535-540
+            break;
+        case K_TRIANGLE:
+        case K_SMOOTH_TRIANGLE:
+            s->p1 = r.v(), s->p2 = r.v(), s->p3 = r.v();
+            s->e1 = sub(s->p2, s->p1);  // primitive.rs:404-409
+            s->e2 = sub(s->p3, s->p1);
+            bounds_add_point(s->bounds, s->p1);  // primitive.rs:442-450
+            bounds_add_point(s->bounds, s->p2);
+            bounds_add_point(s->bounds, s->p3);
+            if (s->kind == K_TRIANGLE) {
+                s->n1 = normalize(cross(s->e1, s->e2));  // primitive.rs:82
+            } else {
+                s->n1 = r.v(), s->n2 = r.v(), s->n3 = r.v();
+            }
+            break;
+        case K_GROUP: {
+            const int n = static_cast<int>(r.next());
+            for (int i = 0; i < n && r.ok; ++i) s->children.push_back(read_shape(r, w, depth + 1));
+            if (!r.ok) return nullptr;
+            Bounds b;  // compound.rs:29-36
+            for (const auto& child : s->children) {
+                bounds_union(b, child->bounds);
+                bounds_transform(b, child->transform);
+            }
+            s->bounds = b;
+            break;
+        }
+        case K_CSG: {
+            s->op = static_cast<int>(r.next());
+            s->children.push_back(read_shape(r, w, depth + 1));
+            s->children.push_back(read_shape(r, w, depth + 1));
+            if (!r.ok) return nullptr;
+            Bounds b;  // compound.rs:38-47
+            bounds_union(b, s->children[0]->bounds);
+            bounds_transform(b, s->children[0]->transform);
+            bounds_union(b, s->children[1]->bounds);
+            bounds_transform(b, s->children[1]->transform);
+            s->bounds = b;
+            break;
+        }
+        default: r.ok = false;
+    }
+    return s;
+}
+
+// Trail of a node given its ancestors (for orc_normal_at): rebuilt by search.
+bool find_trail(const Node& at, const Node* target, const Trail& trail, Trail& out) {
+    if (&at == target) {
+        out = trail;
+        return true;
+    }
+    if (at.is_primitive()) return false;
+    const Trail t = trail.pushed_front(&at.inverse);
+    for (const auto& c : at.children)
+        if (find_trail(*c, target, t, out)) return true;
+    return false;
+}
+
+uint8_t scale_to_ppm_data(double c) {  // canvas.rs:85-90
+    double v = c * 255.0;
+    if (std::isnan(v)) return 0;
+    v = v < 0.0 ? 0.0 : (v > 255.0 ? 255.0 : v);
+    return static_cast<uint8_t>(std::round(v));
+}
+
+}  // namespace
+
+// ================================================================== C API ===
+extern "C" {
+
+void* orc_world_create(const double* desc, size_t n) {
+    Reader r{desc, n};
+    auto w = std::make_unique<World>();
+    const int n_lights = static_cast<int>(r.next());
+    for (int i = 0; i < n_lights && r.ok; ++i) {
+        Light l;
+        l.position = r.v();
+        l.intensity = r.v();
+        w->lights.push_back(l);
+    }
+    const int n_shapes = static_cast<int>(r.next());
+    for (int i = 0; i < n_shapes && r.ok; ++i) w->shapes.push_back(read_shape(r, *w));
+    if (!r.ok || r.i != n) return nullptr;
+    return w.release();
+}
+void orc_world_destroy(void* w) { delete static_cast<World*>(w); }
+int orc_world_num_nodes(void* w) { return static_cast<World*>(w)->n_nodes; }
+
+// Renders image rows row_begin, row_begin+row_step, ... < row_end into the full-frame
+// buffer out_rgb[v_size*h_size*3] (other rows untouched).  Rows are distributed
+// over `nthreads` OpenMP threads with schedule(dynamic,1), mirroring rayon's
+// work stealing over rows (camera.rs:52-54).  ray_counts[4] (optional) receives
+// primary/shadow/reflect/refract ray totals (one per World::intersections call).
+int orc_render(void* world, int h_size, int v_size, double fov, const double* cam_transform16, int cam_transform_set,
+               int depth, int row_begin, int row_end, int row_step, double* out_rgb, int nthreads,
+               uint64_t* ray_counts) {
+    const World& w = *static_cast<World*>(world);
+    Camera cam;
+    if (!camera_new(h_size, v_size, fov, cam_transform16, cam_transform_set, cam)) return -1;
+    if (row_step < 1) row_step = 1;
+    if (row_end > v_size) row_end = v_size;
+    const int n_rows = row_end > row_begin ? (row_end - row_begin + row_step - 1) / row_step : 0;
+    uint64_t tot[4] = {0, 0, 0, 0};
+#ifdef _OPENMP
+    if (nthreads < 1) nthreads = omp_get_max_threads();
+#pragma omp parallel num_threads(nthreads)
+#endif
+    {
+        RayCounts rc;
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
+#endif
+        for (int k = 0; k < n_rows; ++k) {
+            const int y = row_begin + k * row_step;
+            for (int x = 0; x < h_size; ++x) {
+                const Ray ray = ray_for_pixel(cam, x, y);
+                ++rc.primary;
+                const V3 c = color_at(w, ray, depth, &rc);
+                double* o = out_rgb + (static_cast<size_t>(y) * h_size + x) * 3;
+                o[0] = c.x, o[1] = c.y, o[2] = c.z;
+            }
+        }
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+        {
+            tot[0] += rc.primary, tot[1] += rc.shadow, tot[2] += rc.reflect, tot[3] += rc.refract;
+        }
+    }
+    if (ray_counts)
+        for (int i = 0; i < 4; ++i) ray_counts[i] = tot[i];
+    return 0;
+}
+
+void orc_color_at(void* world, const double* rays, int n, int depth, double* out_rgb) {  // world.rs:32
+    const World& w = *static_cast<World*>(world);
+    for (int i = 0; i < n; ++i) {
+        const double* r = rays + 6 * i;
+        const V3 c = color_at(w, Ray{v3(r[0], r[1], r[2]), v3(r[3], r[4], r[5])}, depth, nullptr);
+        out_rgb[3 * i] = c.x, out_rgb[3 * i + 1] = c.y, out_rgb[3 * i + 2] = c.z;
+    }
+}
+
+// out[n*16] = hit, t, shape id, n1, n2, inside, over_point xyz, normal xyz, reflect xyz, is_shadowed(light 0)
+void orc_probe(void* world, const double* rays, int n, double* out) {
+    const World& w = *static_cast<World*>(world);
+    for (int i = 0; i < n; ++i) {
+        const double* r = rays + 6 * i;
+        double* o = out + 16 * i;
+        for (int k = 0; k < 16; ++k) o[k] = 0.0;
+        const Ray ray{v3(r[0], r[1], r[2]), v3(r[3], r[4], r[5])};
+        const Intersections xs = world_intersections(w, ray);
+        const Intersection* hit = find_hit(xs, false);
+        if (!hit) continue;
+        const Computations c = prepare_computations(*hit, ray, xs);
+        o[0] = 1.0, o[1] = hit->t, o[2] = hit->shape->id, o[3] = c.n1, o[4] = c.n2, o[5] = c.inside ? 1.0 : 0.0;
+        o[6] = c.over_point.x, o[7] = c.over_point.y, o[8] = c.over_point.z;
+        o[9] = c.normal_v.x, o[10] = c.normal_v.y, o[11] = c.normal_v.z;
+        o[12] = c.reflect_v.x, o[13] = c.reflect_v.y, o[14] = c.reflect_v.z;
+        o[15] = (!w.lights.empty() && is_shadowed(w, c.over_point, w.lights[0].position, nullptr)) ? 1.0 : 0.0;
+    }
+}
+
+// World::intersections for one ray: sorted t values and shape ids; returns the count.
+int orc_intersect(void* world, const double* ray6, double* ts, int* ids, int cap) {
+    const World& w = *static_cast<World*>(world);
+    const Intersections xs =
+        world_intersections(w, Ray{v3(ray6[0], ray6[1], ray6[2]), v3(ray6[3], ray6[4], ray6[5])});
+    int k = 0;
+    for (const Intersection& i : xs) {
+        if (k < cap) {
+            ts[k] = i.t;
+            ids[k] = i.shape->id;
+        }
+        ++k;
+    }
+    return k;
+}
+
+// Primitive::normal_at (primitive.rs:153) for shape `id` at a WORLD point; u,v for smooth triangles.
+int orc_normal_at(void* world, int id, const double* point3, double u, double v, double* out3) {
+    const World& w = *static_cast<World*>(world);
+    if (id < 0 || id >= w.n_nodes || !w.by_id[id]->is_primitive()) return -1;
+    const Node* s = w.by_id[id];
+    Trail trail, found;
+    bool ok = false;
+    for (const auto& top : w.shapes)
+        if (find_trail(*top, s, trail, found)) {
+            ok = true;
+            break;
+        }
+    if (!ok) return -1;
+    const Intersection hit{0.0, s, true, u, v, found};
+    const V3 n = normal_at(*s, v3(point3[0], point3[1], point3[2]), hit);
+    out3[0] = n.x, out3[1] = n.y, out3[2] = n.z;
+    return 0;
+}
+
+int orc_is_shadowed(void* world, const double* point3, int light) {  // world.rs:85
+    const World& w = *static_cast<World*>(world);
+    return is_shadowed(w, v3(point3[0], point3[1], point3[2]), w.lights[light].position, nullptr) ? 1 : 0;
+}
+
+// Group/CSG bounds as the reference stores them (before the per-ray transform), for KATs.
+int orc_bounds(void* world, int id, double* out6) {
+    const World& w = *static_cast<World*>(world);
+    if (id < 0 || id >= w.n_nodes) return -1;
+    const Bounds& b = w.by_id[id]->bounds;
+    out6[0] = b.minimum.x, out6[1] = b.minimum.y, out6[2] = b.minimum.z;
+    out6[3] = b.maximum.x, out6[4] = b.maximum.y, out6[5] = b.maximum.z;
+    return 0;
+}
+
+// left.includes(primitive `id`) for CSG node `csg_id` (compound.rs:154)
+int orc_csg_includes_left(void* world, int csg_id, int id) {
+    const World& w = *static_cast<World*>(world);
+    const Node* c = w.by_id[csg_id];
+    if (c->kind != K_CSG) return -1;
+    return includes(*c->children[0], *w.by_id[id]) ? 1 : 0;
+}
+
+void orc_ray_for_pixel(int h_size, int v_size, double fov, const double* t16, int set, int px, int py, double* out6) {
+    Camera c;
+    camera_new(h_size, v_size, fov, t16, set, c);
+    const Ray r = ray_for_pixel(c, px, py);
+    out6[0] = r.origin.x, out6[1] = r.origin.y, out6[2] = r.origin.z;
+    out6[3] = r.direction.x, out6[4] = r.direction.y, out6[5] = r.direction.z;
+}
+double orc_camera_pixel_size(int h_size, int v_size, double fov) {
+    Camera c;
+    camera_new(h_size, v_size, fov, nullptr, 0, c);
+    return c.pixel_size;
+}
+
+int orc_matrix_inverse(const double* in16, double* out16) {
+    Mat4 a, r;
+    std::memcpy(a.m, in16, sizeof a.m);
+    if (!mat_inverse(a, r)) return -1;
+    std::memcpy(out16, r.m, sizeof r.m);
+    return 0;
+}
+double orc_matrix_determinant(const double* in16) {
+    Mat4 a;
+    std::memcpy(a.m, in16, sizeof a.m);
+    return det4(a);
+}
+void orc_matrix_mul(const double* a16, const double* b16, double* out16) {
+    Mat4 a, b;
+    std::memcpy(a.m, a16, sizeof a.m);
+    std::memcpy(b.m, b16, sizeof b.m);
+    const Mat4 r = mat_mul(a, b);
+    std::memcpy(out16, r.m, sizeof r.m);
+}
+
+double orc_schlick(const double* eye3, const double* normal3, double n1, double n2) {
+    Computations c{};
+    c.eye_v = v3(eye3[0], eye3[1], eye3[2]);
+    c.normal_v = v3(normal3[0], normal3[1], normal3[2]);
+    c.n1 = n1, c.n2 = n2;
+    return schlick(c);
+}
+int orc_intersection_allowed(int op, int l_hit, int in_l, int in_r) {
+    return intersection_allowed(op, l_hit != 0, in_l != 0, in_r != 0) ? 1 : 0;
+}
+double orc_perturb_noise(double x, double y, double z) { return perturb_noise(x, y, z); }
+
+void orc_quantize(const double* rgb, size_t n_values, uint8_t* out) {
+    for (size_t i = 0; i < n_values; ++i) out[i] = scale_to_ppm_data(rgb[i]);
+}
+
+// Canvas::to_ppm (canvas.rs:46-83).  Returns the byte length; writes at most `cap` bytes.
+size_t orc_to_ppm(const double* rgb, int width, int height, char* out, size_t cap) {
+    std::string ppm = "P3\n" + std::to_string(width) + " " + std::to_string(height) + "\n255\n";
+    for (int row = 0; row < height; ++row) {
+        std::vector<std::string> colors;
+        for (int x = 0; x < width; ++x)
+            for (int ch = 0; ch < 3; ++ch)
+                colors.push_back(std::to_string(scale_to_ppm_data(rgb[(static_cast<size_t>(row) * width + x) * 3 + ch])));
+        size_t next = 0;
+        while (next < colors.size()) {  // `while colors.peek().is_some()`
+            size_t line_len = 0;
+            std::string line;
+            bool first = true;
+            while (next < colors.size()) {  // take_while_ref
+                line_len += colors[next].size() + 1;
+                if (!(line_len <= 70)) break;
+                if (!first) line += " ";
+                line += colors[next++];
+                first = false;
+            }
+            ppm += line;
+            ppm += '\n';
+        }
+    }
+    if (out && cap > 0) std::memcpy(out, ppm.data(), ppm.size() < cap ? ppm.size() : cap);
+    return ppm.size();
+}
+
+// exercises/shading.rs:17-63: the hand-rolled sphere shader behind images/ppm/shading.ppm.
+// out_rgb[500*500*3], untouched pixels stay BLACK.
+void orc_exercise_shading(double* out_rgb) {
+    const int side_len = 500;
+    for (int i = 0; i < side_len * side_len * 3; ++i) out_rgb[i] = 0.0;
+    const V3 ray_origin = v3(0.0, 0.0, -5.0);
+    const double wall_z = 10.0, wall_size = 7.0;
+    const double pixel_size = wall_size / static_cast<double>(side_len);
+    const double half = wall_size / 2.0;
+    Node sphere;
+    sphere.kind = K_SPHERE;
+    sphere.bounds = Bounds{v3(-1, -1, -1), v3(1, 1, 1)};
+    sphere.material.color = v3(1.0, 0.2, 1.0);
+    const Light light{v3(-10.0, 10.0, -10.0), v3(1.0, 1.0, 1.0)};
+    const Trail empty{};
+    for (int y = 0; y < side_len; ++y) {
+        const double world_y = half - pixel_size * static_cast<double>(y);
+        for (int x = 0; x < side_len; ++x) {
+            const double world_x = -half + pixel_size * static_cast<double>(x);
+            const V3 position = v3(world_x, world_y, wall_z);
+            const Ray r{ray_origin, normalize(sub(position, ray_origin))};
+            const Intersections xs = intersect(sphere, r, empty);
+            const Intersection* hit = find_hit(xs, false);
+            if (!hit) continue;
+            const V3 point = ray_position(r, hit->t);
+            const Intersection probe{0.0, &sphere, false, 0.0, 0.0, empty};
+            const V3 normal = normal_at(sphere, point, probe);
+            const V3 eye = neg(r.direction);
+            const V3 color = lighting(*hit->shape, point, light, eye, normal, false, empty);
+            double* o = out_rgb + (static_cast<size_t>(y) * side_len + x) * 3;
+            o[0] = color.x, o[1] = color.y, o[2] = color.z;
+        }
+    }
+}
+
+int orc_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+}  // extern "C"

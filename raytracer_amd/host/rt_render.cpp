@@ -1,0 +1,51 @@
+// The two calls of the reference API that trace rays -- Camera::render
+// (camera.rs:51) and World::color_at (world.rs:32) -- implemented as
+// flatten + one call through the C ABI of include/rt_hip.h.  There is no CPU
+// path here: if the HIP library reports an error (no device included) the call
+// throws rt::RenderError.
+#include <string>
+
+#include "rt_flatten.h"
+#include "rt_scene.h"
+
+namespace rt {
+namespace {
+[[noreturn]] void fail(int code, const char* where) {
+    std::string msg = std::string(where) + ": " + rt_hip_strerror(code);
+    const char* hip = rt_hip_last_hip_error();
+    if (hip && *hip) msg += std::string(" (") + hip + ")";
+    throw RenderError(code, msg);
+}
+}  // namespace
+
+Canvas Camera::render(const World& world) const {
+    const FlatScene flat = flatten(world);
+    const RtSceneDesc desc = flat.desc();
+    const RtCameraDesc cam = camera_desc(*this);
+    static_assert(sizeof(Color) == 3 * sizeof(double), "Color must be three packed doubles");
+    std::vector<Color> pixels(h_size_ * v_size_);
+    const int rc = rt_hip_render(&desc, &cam, kDepth, reinterpret_cast<double*>(pixels.data()), nullptr);
+    if (rc != RT_OK) fail(rc, "Camera::render");
+    return Canvas(h_size_, v_size_, std::move(pixels));
+}
+
+std::vector<Color> World::color_at(const std::vector<Ray>& rays, uint8_t remaining_recursions) const {
+    const FlatScene flat = flatten(*this);
+    const RtSceneDesc desc = flat.desc();
+    RtScene* scene = nullptr;
+    int rc = rt_hip_scene_create(&desc, &scene);
+    if (rc != RT_OK) fail(rc, "World::color_at");
+    static_assert(sizeof(Ray) == 6 * sizeof(double), "Ray must be six packed doubles");
+    std::vector<Color> out(rays.size());
+    rc = rt_hip_color_at(scene, reinterpret_cast<const double*>(rays.data()), static_cast<uint32_t>(rays.size()),
+                         remaining_recursions, reinterpret_cast<double*>(out.data()));
+    rt_hip_scene_destroy(scene);
+    if (rc != RT_OK) fail(rc, "World::color_at");
+    return out;
+}
+
+Color World::color_at(const Ray& ray, uint8_t remaining_recursions) const {
+    return color_at(std::vector<Ray>{ray}, remaining_recursions)[0];
+}
+
+}  // namespace rt

@@ -1,0 +1,579 @@
+// Scene-construction half of the host mirror (see rt_scene.h).  Everything in
+// this file runs once per scene on the host; none of it is on the per-pixel path.
+#include "rt_scene.h"
+
+#include <cerrno>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <unordered_map>
+
+namespace rt {
+
+// ------------------------------------------------------------------ Pattern ---
+Pattern Pattern::new_solid(const Color& c) {
+    Pattern p;
+    p.kind_ = Kind::Solid;
+    p.color_ = c;
+    return p;
+}
+Pattern Pattern::new_perturb(const Pattern& child) {
+    Pattern p;
+    p.kind_ = Kind::Perturb;
+    p.a_ = std::make_shared<const Pattern>(child);
+    return p;
+}
+Pattern Pattern::new_test() {
+    Pattern p;
+    p.kind_ = Kind::Test;
+    return p;
+}
+Pattern Pattern::mixture(Kind k, const Pattern& a, const Pattern& b) {
+    Pattern p;
+    p.kind_ = k;
+    p.a_ = std::make_shared<const Pattern>(a);
+    p.b_ = std::make_shared<const Pattern>(b);
+    return p;
+}
+Pattern Pattern::with_transform(const Matrix4& t) const {
+    Pattern p = *this;
+    p.transform_ = t;
+    p.inverse_ = t.inverse();
+    p.transform_set_ = true;
+    return p;
+}
+bool Pattern::structural_eq(const Pattern& o) const {
+    if (!transform_.approx_eq(o.transform_) || !inverse_.approx_eq(o.inverse_)) return false;
+    if (kind_ != o.kind_) return false;
+    switch (kind_) {
+        case Kind::Solid: return approx_eq(color_, o.color_);
+        case Kind::Test: return true;
+        case Kind::Perturb: return a_->structural_eq(*o.a_);
+        default: return a_->structural_eq(*o.a_) && b_->structural_eq(*o.b_);
+    }
+}
+
+// ----------------------------------------------------------------- Material ---
+bool Material::structural_eq(const Material& o) const {  // material.rs:47-59
+    if (!approx_eq(color, o.color)) return false;
+    if (!abs_diff_eq(ambient, o.ambient, 1e-5) || !abs_diff_eq(diffuse, o.diffuse, 1e-5) ||
+        !abs_diff_eq(specular, o.specular, 1e-5) || !abs_diff_eq(shininess, o.shininess, 1e-5) ||
+        !abs_diff_eq(reflective, o.reflective, 1e-5) ||
+        !abs_diff_eq(transparency, o.transparency, 1e-5) ||
+        !abs_diff_eq(refractive_index, o.refractive_index, 1e-5))
+        return false;
+    if (pattern.has_value() != o.pattern.has_value()) return false;
+    return !pattern.has_value() || pattern->structural_eq(*o.pattern);
+}
+
+// ------------------------------------------------------------------- Bounds ---
+void Bounds::add_point(const Point& p) {
+    minimum.x = std::fmin(minimum.x, p.x);
+    minimum.y = std::fmin(minimum.y, p.y);
+    minimum.z = std::fmin(minimum.z, p.z);
+    maximum.x = std::fmax(maximum.x, p.x);
+    maximum.y = std::fmax(maximum.y, p.y);
+    maximum.z = std::fmax(maximum.z, p.z);
+}
+void Bounds::union_with(const Bounds& o) {
+    add_point(o.minimum);
+    add_point(o.maximum);
+}
+void Bounds::transform(const Matrix4& t) {
+    // corner order of bounds.rs:20-29, captured before the box starts growing
+    const Point c[8] = {minimum,
+                        Point(minimum.x, minimum.y, maximum.z),
+                        Point(minimum.x, maximum.y, minimum.z),
+                        Point(minimum.x, maximum.y, maximum.z),
+                        Point(maximum.x, minimum.y, minimum.z),
+                        Point(maximum.x, minimum.y, maximum.z),
+                        Point(maximum.x, maximum.y, minimum.z),
+                        maximum};
+    for (const Point& corner : c) add_point(t * corner);
+}
+bool Bounds::structural_eq(const Bounds& o) const {
+    return approx_eq(minimum, o.minimum) && approx_eq(maximum, o.maximum);
+}
+
+// ---------------------------------------------------------------- Primitive ---
+Primitive::Primitive(Kind k) : kind_(k) {}
+
+static Bounds unit_box() { return Bounds(Point(-1.0, -1.0, -1.0), Point(1.0, 1.0, 1.0)); }
+
+Primitive Primitive::new_sphere() {
+    Primitive p(Kind::Sphere);
+    p.props_.bounds = unit_box();  // primitive.rs:38-40
+    return p;
+}
+Primitive Primitive::new_glass_sphere() {  // primitive.rs:56-62
+    Material m;
+    m.transparency = 1.0;
+    m.refractive_index = 1.5;
+    return new_sphere().with_material(m);
+}
+Primitive Primitive::new_plane() {
+    Primitive p(Kind::Plane);
+    const double inf = std::numeric_limits<double>::infinity();
+    p.props_.bounds = Bounds(Point(-inf, 0.0, -inf), Point(inf, 0.0, inf));  // primitive.rs:41-44
+    return p;
+}
+Primitive Primitive::new_cube() {
+    Primitive p(Kind::Cube);
+    p.props_.bounds = unit_box();
+    return p;
+}
+Primitive Primitive::new_cylinder(const Conic& c) {
+    Primitive p(Kind::Cylinder);
+    p.conic_ = c;
+    p.props_.bounds = Bounds(Point(-1.0, c.minimum, -1.0), Point(1.0, c.maximum, 1.0));  // :535-540
+    return p;
+}
+Primitive Primitive::new_cone(const Conic& c) {
+    Primitive p(Kind::Cone);
+    p.conic_ = c;
+    p.props_.bounds = Bounds(Point(-1.0, c.minimum, -1.0), Point(1.0, c.maximum, 1.0));
+    return p;
+}
+static void set_triangular(Primitive& p, const Point& p1, const Point& p2, const Point& p3, Bounds& b) {
+    p.p1 = p1, p.p2 = p2, p.p3 = p3;
+    p.e1 = p2 - p1;  // primitive.rs:404-409
+    p.e2 = p3 - p1;
+    b = Bounds();
+    b.add_point(p1);  // primitive.rs:442-450
+    b.add_point(p2);
+    b.add_point(p3);
+}
+Primitive Primitive::new_triangle(const Point& p1, const Point& p2, const Point& p3) {
+    Primitive p(Kind::Triangle);
+    set_triangular(p, p1, p2, p3, p.props_.bounds);
+    p.n1 = p.e1.cross(p.e2).normalize();  // primitive.rs:82
+    return p;
+}
+Primitive Primitive::new_smooth_triangle(const Point& p1, const Point& p2, const Point& p3,
+                                         const Vector& n1, const Vector& n2, const Vector& n3) {
+    Primitive p(Kind::SmoothTriangle);
+    set_triangular(p, p1, p2, p3, p.props_.bounds);
+    p.n1 = n1, p.n2 = n2, p.n3 = n3;
+    return p;
+}
+Primitive Primitive::with_transform(const Matrix4& t) const {  // shape.rs:63-67
+    Primitive p = *this;
+    p.props_.transform = t;
+    p.props_.inverse_transform = t.inverse();
+    p.props_.transform_set = true;
+    return p;
+}
+Primitive Primitive::with_material(const Material& m) const {
+    Primitive p = *this;
+    p.props_.material = m;
+    return p;
+}
+Primitive Primitive::with_shadow(bool s) const {
+    Primitive p = *this;
+    p.has_shadow_ = s;
+    return p;
+}
+Shape Primitive::to_shape() const { return Shape(*this); }
+
+static bool conic_eq(const Conic& a, const Conic& b) {  // primitive.rs:553-571, eps 1e-5
+    return abs_diff_eq(a.minimum, b.minimum, 1e-5) && abs_diff_eq(a.maximum, b.maximum, 1e-5) &&
+           a.closed == b.closed;
+}
+bool Primitive::structural_eq(const Primitive& o) const {
+    const Properties &a = props_, &b = o.props_;
+    if (!a.transform.approx_eq(b.transform) || !a.inverse_transform.approx_eq(b.inverse_transform))
+        return false;
+    if (!a.material.structural_eq(b.material)) return false;
+    if (!a.bounds.structural_eq(b.bounds)) return false;  // false for any infinite box (Q7)
+    if (has_shadow_ != o.has_shadow_ || kind_ != o.kind_) return false;
+    switch (kind_) {
+        case Kind::Cylinder:
+        case Kind::Cone: return conic_eq(conic_, o.conic_);
+        case Kind::Triangle:
+            return approx_eq(p1, o.p1) && approx_eq(p2, o.p2) && approx_eq(p3, o.p3) &&
+                   approx_eq(e1, o.e1) && approx_eq(e2, o.e2) && approx_eq(n1, o.n1);
+        case Kind::SmoothTriangle:
+            return approx_eq(p1, o.p1) && approx_eq(p2, o.p2) && approx_eq(p3, o.p3) &&
+                   approx_eq(e1, o.e1) && approx_eq(e2, o.e2) && approx_eq(n1, o.n1) &&
+                   approx_eq(n2, o.n2) && approx_eq(n3, o.n3);
+        default: return true;
+    }
+}
+
+// ----------------------------------------------------------------- Compound ---
+Compound Compound::new_group(const std::vector<Shape>& children) {
+    Compound c;
+    c.kind_ = Kind::Group;
+    c.children_ = std::make_shared<const std::vector<Shape>>(children);
+    Bounds b;  // compound.rs:29-36: union with the child's box, then grow by the child's transform
+    for (const Shape& child : children) {
+        b.union_with(child.properties().bounds);
+        b.transform(child.properties().transform);
+    }
+    c.props_.bounds = b;
+    return c;
+}
+Compound Compound::new_csg(Operation op, const Shape& left, const Shape& right) {
+    Compound c;
+    c.kind_ = Kind::Csg;
+    c.op_ = op;
+    c.children_ = std::make_shared<const std::vector<Shape>>(std::vector<Shape>{left, right});
+    Bounds b;  // compound.rs:38-47
+    b.union_with(left.properties().bounds);
+    b.transform(left.properties().transform);
+    b.union_with(right.properties().bounds);
+    b.transform(right.properties().transform);
+    c.props_.bounds = b;
+    return c;
+}
+Compound Compound::with_transform(const Matrix4& t) const {
+    Compound c = *this;
+    c.props_.transform = t;
+    c.props_.inverse_transform = t.inverse();
+    c.props_.transform_set = true;
+    return c;
+}
+Compound Compound::with_material(const Material& m) const {
+    Compound c = *this;
+    c.props_.material = m;
+    return c;
+}
+Shape Compound::to_shape() const { return Shape(*this); }
+bool Compound::includes(const Primitive& other) const {
+    for (const Shape& s : *children_)
+        if (s.includes(other)) return true;
+    return false;
+}
+bool Shape::includes(const Primitive& other) const {
+    return is_primitive() ? primitive().structural_eq(other) : compound().includes(other);
+}
+
+// ------------------------------------------------------------------- Canvas ---
+Canvas::Canvas(size_t width, size_t height, std::vector<Color> pixels)
+    : width_(width), height_(height), pixels_(std::move(pixels)) {}
+Canvas Canvas::empty(size_t width, size_t height) {
+    return Canvas(width, height, std::vector<Color>(width * height, Color::BLACK()));
+}
+uint8_t Canvas::scale_to_ppm_data(double c) {
+    double v = c * 255.0;
+    if (std::isnan(v)) return 0;  // Rust `as u8` maps NaN to 0
+    if (v < 0.0) v = 0.0;
+    if (v > 255.0) v = 255.0;
+    return static_cast<uint8_t>(std::round(v));  // half away from zero, like f64::round
+}
+std::string Canvas::to_ppm() const {
+    std::string out = "P3\n" + std::to_string(width_) + " " + std::to_string(height_) + "\n255\n";
+    out.reserve(out.size() + pixels_.size() * 12);
+    char tok[8];
+    for (size_t row = 0; row < height_; ++row) {
+        // canvas.rs:68-79: a token joins the current line while the running sum of
+        // (token length + 1) stays <= 70; the sum restarts with each line.
+        size_t line_len = 0;
+        bool first = true;
+        for (size_t x = 0; x < width_; ++x) {
+            const Color& c = pixels_[row * width_ + x];
+            const uint8_t ch[3] = {scale_to_ppm_data(c.red), scale_to_ppm_data(c.green),
+                                   scale_to_ppm_data(c.blue)};
+            for (uint8_t v : ch) {
+                const int n = std::snprintf(tok, sizeof tok, "%u", static_cast<unsigned>(v));
+                if (!first && line_len + n + 1 > 70) {
+                    out.push_back('\n');
+                    line_len = 0;
+                    first = true;
+                }
+                if (!first) out.push_back(' ');
+                out.append(tok, n);
+                line_len += n + 1;
+                first = false;
+            }
+        }
+        if (width_ > 0) out.push_back('\n');
+    }
+    return out;
+}
+void Canvas::write_ppm(const std::string& path) const {
+    std::ofstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error("file should be written successfully: " + path);
+    const std::string s = to_ppm();
+    f.write(s.data(), static_cast<std::streamsize>(s.size()));
+    if (!f) throw std::runtime_error("file should be written successfully: " + path);
+}
+
+// ------------------------------------------------------------------- World ---
+World World::default_world() {  // world.rs:130-145
+    Material m1;
+    m1.color = Color(0.8, 1.0, 0.6);
+    m1.diffuse = 0.7;
+    m1.specular = 0.2;
+    Primitive s1 = Primitive::new_sphere().with_material(m1);
+    Primitive s2 = Primitive::new_sphere().with_transform(Matrix4::scaling(0.5, 0.5, 0.5));
+    return World({s1.to_shape(), s2.to_shape()},
+                 {PointLight(Point(-10.0, 10.0, -10.0), Color::WHITE())});
+}
+
+// ------------------------------------------------------------------ Camera ---
+Camera::Camera(size_t h_size, size_t v_size, double field_of_view)
+    : h_size_(h_size), v_size_(v_size), fov_(field_of_view) {
+    const double half_view = std::tan(field_of_view / 2.0);  // camera.rs:25
+    const double aspect = static_cast<double>(h_size) / static_cast<double>(v_size);
+    if (aspect >= 1.0) {
+        half_width_ = half_view;
+        half_height_ = half_view / aspect;
+    } else {
+        half_width_ = half_view * aspect;
+        half_height_ = half_view;
+    }
+    pixel_size_ = (half_width_ * 2.0) / static_cast<double>(h_size);  // camera.rs:41
+}
+Camera Camera::with_transform(const Matrix4& t) const {
+    Camera c = *this;
+    c.transform_ = t;
+    c.inverse_ = t.inverse();
+    c.transform_set_ = true;
+    return c;
+}
+
+// --------------------------------------------------------------------- OBJ ---
+namespace obj {
+namespace {
+// Rust's str::parse::<f64>: decimal float syntax, whole token, no whitespace.
+bool parse_f64(const std::string& s, double& out) {
+    if (s.empty() || std::isspace(static_cast<unsigned char>(s[0]))) return false;
+    if (s.find_first_of("xX") != std::string::npos) return false;  // strtod would take hex floats
+    char* end = nullptr;
+    errno = 0;
+    out = std::strtod(s.c_str(), &end);
+    return end == s.c_str() + s.size();
+}
+bool parse_usize(const std::string& s, size_t& out) {
+    if (s.empty()) return false;
+    size_t i = (s[0] == '+') ? 1 : 0;  // usize::from_str accepts a leading '+'
+    if (i == s.size()) return false;
+    size_t v = 0;
+    for (; i < s.size(); ++i) {
+        if (s[i] < '0' || s[i] > '9') return false;
+        v = v * 10 + static_cast<size_t>(s[i] - '0');
+    }
+    out = v;
+    return true;
+}
+std::vector<std::string> split(const std::string& s, char sep) {
+    std::vector<std::string> parts;
+    size_t start = 0;
+    while (true) {
+        const size_t pos = s.find(sep, start);
+        if (pos == std::string::npos) {
+            parts.push_back(s.substr(start));
+            break;
+        }
+        parts.push_back(s.substr(start, pos - start));
+        start = pos + 1;
+    }
+    return parts;
+}
+std::string trim(const std::string& s) {
+    size_t b = 0, e = s.size();
+    while (b < e && std::isspace(static_cast<unsigned char>(s[b]))) ++b;
+    while (e > b && std::isspace(static_cast<unsigned char>(s[e - 1]))) --e;
+    return s.substr(b, e - b);
+}
+struct VertexRef {
+    Point p;
+    bool has_n = false;
+    Vector n;
+};
+VertexRef parse_vertex_ref(const std::string& v, const std::vector<Point>& vertices,
+                           const std::vector<Vector>& normals) {  // obj.rs:164-185
+    const auto parts = split(v, '/');
+    const auto bad = [&]() {
+        return ParseError(ParseError::Kind::Syntax,
+                          "Syntax error, indices must be natural numbers, given: " + v);
+    };
+    VertexRef r;
+    size_t vi = 0, ni = 0;
+    if (parts.size() == 3) {
+        if (!parse_usize(parts[0], vi) || !parse_usize(parts[2], ni)) throw bad();
+        r.p = vertices.at(vi - 1);  // out of range panics in the reference
+        r.n = normals.at(ni - 1);
+        r.has_n = true;
+    } else if (parts.size() == 1 || parts.size() == 2) {
+        if (!parse_usize(parts[0], vi)) throw bad();
+        r.p = vertices.at(vi - 1);
+    } else {
+        throw ParseError(ParseError::Kind::Syntax, "Syntax error, invalid vertex ref: " + v);
+    }
+    return r;
+}
+Primitive parse_triangle(const std::string& a, const std::string& b, const std::string& c,
+                         const std::vector<Point>& vertices, const std::vector<Vector>& normals) {
+    const VertexRef r1 = parse_vertex_ref(a, vertices, normals);
+    const VertexRef r2 = parse_vertex_ref(b, vertices, normals);
+    const VertexRef r3 = parse_vertex_ref(c, vertices, normals);
+    if (r1.has_n && r2.has_n && r3.has_n)
+        return Primitive::new_smooth_triangle(r1.p, r2.p, r3.p, r1.n, r2.n, r3.n);
+    if (!r1.has_n && !r2.has_n && !r3.has_n) return Primitive::new_triangle(r1.p, r2.p, r3.p);
+    throw ParseError(ParseError::Kind::Syntax, "Syntax error, invalid triangle: " + a + " " + b + " " + c);
+}
+}  // namespace
+
+Shape parse_string(const std::string& text, size_t* ignored_lines) {
+    std::vector<Shape> shapes;
+    std::vector<Point> vertices;
+    std::vector<Vector> normals;
+    // The reference keeps named groups in a HashMap (obj.rs:36) whose iteration
+    // order is unspecified; first-seen order is used here so results are repeatable.
+    std::vector<std::string> group_order;
+    std::unordered_map<std::string, std::vector<Primitive>> groups;
+    bool have_group = false;
+    std::string current_group;
+    size_t ignored = 0;
+
+    std::istringstream in(text);
+    std::string line;
+    while (std::getline(in, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();  // str::lines strips \r\n
+        const auto tok = split(trim(line), ' ');                   // obj.rs:76: single-space split
+        if (tok.size() == 4 && (tok[0] == "v" || tok[0] == "vn")) {
+            double x, y, z;
+            if (!parse_f64(tok[1], x) || !parse_f64(tok[2], y) || !parse_f64(tok[3], z))
+                throw ParseError(ParseError::Kind::Syntax,
+                                 std::string("Syntax error, invalid ") + (tok[0] == "v" ? "vertex" : "normal") +
+                                     ": " + tok[1] + " " + tok[2] + " " + tok[3]);
+            if (tok[0] == "v")
+                vertices.emplace_back(x, y, z);
+            else
+                normals.emplace_back(x, y, z);
+        } else if (tok.size() >= 4 && tok[0] == "f") {
+            std::vector<Primitive> ts;  // fan triangulation, obj.rs:132-140
+            for (size_t i = 2; i + 1 < tok.size(); ++i)
+                ts.push_back(parse_triangle(tok[1], tok[i], tok[i + 1], vertices, normals));
+            if (have_group) {
+                auto it = groups.find(current_group);
+                if (it == groups.end()) {
+                    group_order.push_back(current_group);
+                    it = groups.emplace(current_group, std::vector<Primitive>()).first;
+                }
+                it->second.insert(it->second.end(), ts.begin(), ts.end());
+            } else {
+                for (const Primitive& t : ts) shapes.push_back(t.to_shape());
+            }
+        } else if (tok.size() == 2 && tok[0] == "g") {
+            have_group = true;
+            current_group = tok[1];
+        } else {
+            ++ignored;
+        }
+    }
+    if (ignored_lines) *ignored_lines = ignored;
+
+    for (const std::string& name : group_order) {  // obj.rs:40-45
+        std::vector<Shape> kids;
+        for (const Primitive& t : groups[name]) kids.push_back(t.to_shape());
+        shapes.push_back(Compound::new_group(kids).to_shape());
+    }
+    if (shapes.empty()) throw ParseError(ParseError::Kind::Logic, "Logic error, no shapes found");
+    if (shapes.size() == 1) return shapes.back();
+    return Compound::new_group(shapes).to_shape();
+}
+
+Shape parse_file(const std::string& path) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw ParseError(ParseError::Kind::Io, "IO error, cannot read " + path);
+    std::stringstream ss;
+    ss << f.rdbuf();
+    return parse_string(ss.str());
+}
+}  // namespace obj
+
+// ---------------------------------------------------------------- describe ---
+namespace {
+void put_matrix(std::vector<double>& out, const Matrix4& m) {
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) out.push_back(m.m[i][j]);
+}
+void put_pattern(std::vector<double>& out, const Pattern& p) {
+    out.push_back(static_cast<double>(static_cast<uint32_t>(p.kind())));
+    out.push_back(p.transform_was_set() ? 1.0 : 0.0);
+    put_matrix(out, p.transform());
+    switch (p.kind()) {
+        case Pattern::Kind::Solid:
+            out.push_back(p.color().red), out.push_back(p.color().green), out.push_back(p.color().blue);
+            break;
+        case Pattern::Kind::Test: break;
+        case Pattern::Kind::Perturb: put_pattern(out, *p.a()); break;
+        default:
+            put_pattern(out, *p.a());
+            put_pattern(out, *p.b());
+    }
+}
+void put_material(std::vector<double>& out, const Material& m) {
+    out.push_back(m.color.red), out.push_back(m.color.green), out.push_back(m.color.blue);
+    out.push_back(m.ambient), out.push_back(m.diffuse), out.push_back(m.specular);
+    out.push_back(m.shininess), out.push_back(m.reflective), out.push_back(m.transparency);
+    out.push_back(m.refractive_index);
+    out.push_back(m.pattern ? 1.0 : 0.0);
+    if (m.pattern) put_pattern(out, *m.pattern);
+}
+void put_point(std::vector<double>& out, double x, double y, double z) {
+    out.push_back(x), out.push_back(y), out.push_back(z);
+}
+void put_shape(std::vector<double>& out, const Shape& s) {
+    const Properties& pr = s.properties();
+    if (s.is_primitive()) {
+        const Primitive& p = s.primitive();
+        out.push_back(static_cast<double>(static_cast<uint32_t>(p.kind())));
+        out.push_back(p.has_shadow() ? 1.0 : 0.0);
+        out.push_back(pr.transform_set ? 1.0 : 0.0);
+        put_matrix(out, pr.transform);
+        put_material(out, pr.material);
+        switch (p.kind()) {
+            case Primitive::Kind::Cylinder:
+            case Primitive::Kind::Cone:
+                out.push_back(p.conic().minimum), out.push_back(p.conic().maximum);
+                out.push_back(p.conic().closed ? 1.0 : 0.0);
+                break;
+            case Primitive::Kind::Triangle:
+            case Primitive::Kind::SmoothTriangle:
+                put_point(out, p.p1.x, p.p1.y, p.p1.z);
+                put_point(out, p.p2.x, p.p2.y, p.p2.z);
+                put_point(out, p.p3.x, p.p3.y, p.p3.z);
+                if (p.kind() == Primitive::Kind::SmoothTriangle) {
+                    put_point(out, p.n1.x, p.n1.y, p.n1.z);
+                    put_point(out, p.n2.x, p.n2.y, p.n2.z);
+                    put_point(out, p.n3.x, p.n3.y, p.n3.z);
+                }
+                break;
+            default: break;
+        }
+    } else {
+        const Compound& c = s.compound();
+        out.push_back(static_cast<double>(static_cast<uint32_t>(c.kind())));
+        out.push_back(1.0);
+        out.push_back(pr.transform_set ? 1.0 : 0.0);
+        put_matrix(out, pr.transform);
+        put_material(out, pr.material);
+        if (c.kind() == Compound::Kind::Csg) {
+            out.push_back(static_cast<double>(static_cast<uint32_t>(c.operation())));
+        } else {
+            out.push_back(static_cast<double>(c.children().size()));
+        }
+        for (const Shape& child : c.children()) put_shape(out, child);
+    }
+}
+}  // namespace
+
+std::vector<double> describe_world(const World& w) {
+    std::vector<double> out;
+    out.push_back(static_cast<double>(w.lights().size()));
+    for (const PointLight& l : w.lights()) {
+        put_point(out, l.position.x, l.position.y, l.position.z);
+        put_point(out, l.intensity.red, l.intensity.green, l.intensity.blue);
+    }
+    out.push_back(static_cast<double>(w.shapes().size()));
+    for (const Shape& s : w.shapes()) put_shape(out, s);
+    return out;
+}
+
+}  // namespace rt
