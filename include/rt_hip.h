@@ -257,6 +257,12 @@ int rt_hip_render_rows(const RtScene* scene, const RtCameraDesc* cam, uint32_t d
                        uint32_t n_parts, uint32_t band_rows, uint32_t n_local_rows,
                        double* d_out_rgb, void* hip_stream, RtStats* d_stats);
 
+/* Run-time conditions raised by launches on this scene since the last call (RT_ERR_LIST_OVERFLOW,
+ * RT_ERR_NAN_T) or RT_OK; synchronises `hip_stream` and clears them.  The blocking entry points
+ * call this themselves; rt_hip_render_rows is asynchronous and leaves it to the caller.
+ * Replaces: the reference's panics on the same conditions (intersection.rs:119). */
+int rt_hip_scene_status(const RtScene* scene, void* hip_stream);
+
 /* Drop-in for `World::color_at(&self, ray, remaining) -> Color` (world.rs:32-43)
  * over a batch: rays[n*6] = origin xyz, direction xyz (HOST), out_rgb[n*3] (HOST). */
 int rt_hip_color_at(const RtScene* scene, const double* rays, uint32_t n, uint32_t depth,

@@ -1,0 +1,185 @@
+"""ctypes face of the CPU oracle (oracle/librt_oracle.so).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and the cpu_baseline leg of bench.py import this
+module; nothing under raytracer_amd/ does.  The oracle receives scenes as the object-tree
+description produced by World.describe() and derives everything (inverses, bounds, CSG
+membership) itself.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PATH = os.path.join(_HERE, "librt_oracle.so")
+if not os.path.exists(_PATH):
+    raise ImportError(f"{_PATH} is missing: run `make -C oracle`")
+lib = C.CDLL(_PATH)
+
+_dp = C.POINTER(C.c_double)
+_vp = C.c_void_p
+
+
+def _sig(name, restype, *argtypes):
+    fn = getattr(lib, name)
+    fn.restype, fn.argtypes = restype, list(argtypes)
+
+
+_sig("orc_world_create", _vp, _dp, C.c_size_t)
+_sig("orc_world_destroy", None, _vp)
+_sig("orc_world_num_nodes", C.c_int, _vp)
+_sig("orc_render", C.c_int, _vp, C.c_int, C.c_int, C.c_double, _dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp,
+     C.c_int, C.POINTER(C.c_uint64))
+_sig("orc_color_at", None, _vp, _dp, C.c_int, C.c_int, _dp)
+_sig("orc_probe", None, _vp, _dp, C.c_int, _dp)
+_sig("orc_intersect", C.c_int, _vp, _dp, _dp, C.POINTER(C.c_int), C.c_int)
+_sig("orc_normal_at", C.c_int, _vp, C.c_int, _dp, C.c_double, C.c_double, _dp)
+_sig("orc_is_shadowed", C.c_int, _vp, _dp, C.c_int)
+_sig("orc_bounds", C.c_int, _vp, C.c_int, _dp)
+_sig("orc_csg_includes_left", C.c_int, _vp, C.c_int, C.c_int)
+_sig("orc_ray_for_pixel", None, C.c_int, C.c_int, C.c_double, _dp, C.c_int, C.c_int, C.c_int, _dp)
+_sig("orc_camera_pixel_size", C.c_double, C.c_int, C.c_int, C.c_double)
+_sig("orc_matrix_inverse", C.c_int, _dp, _dp)
+_sig("orc_matrix_determinant", C.c_double, _dp)
+_sig("orc_matrix_mul", None, _dp, _dp, _dp)
+_sig("orc_schlick", C.c_double, _dp, _dp, C.c_double, C.c_double)
+_sig("orc_intersection_allowed", C.c_int, C.c_int, C.c_int, C.c_int, C.c_int)
+_sig("orc_perturb_noise", C.c_double, C.c_double, C.c_double, C.c_double)
+_sig("orc_quantize", None, _dp, C.c_size_t, C.POINTER(C.c_uint8))
+_sig("orc_to_ppm", C.c_size_t, _dp, C.c_int, C.c_int, C.c_char_p, C.c_size_t)
+_sig("orc_exercise_shading", None, _dp)
+_sig("orc_max_threads", C.c_int)
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _arr(a, n=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if n is not None:
+        a = a.reshape(n)
+    return a
+
+
+class OracleWorld:
+    def __init__(self, description):
+        d = _arr(description).reshape(-1)
+        self._w = lib.orc_world_create(_p(d), d.size)
+        if not self._w:
+            raise ValueError("oracle could not parse the world description")
+
+    def __del__(self):
+        w, self._w = getattr(self, "_w", None), None
+        if w:
+            lib.orc_world_destroy(w)
+
+    @property
+    def num_nodes(self):
+        return lib.orc_world_num_nodes(self._w)
+
+    def render(self, camera, depth=5, rows=None, nthreads=0, out=None):
+        """Render `rows` = (begin, end, step) (default: all) of `camera` (an api.Camera).
+        Returns (frame [v,h,3] with untouched rows left as they were, ray_counts[4])."""
+        h, v = camera.h_size, camera.v_size
+        if out is None:
+            out = np.zeros((v, h, 3), dtype=np.float64)
+        b, e, s = rows if rows is not None else (0, v, 1)
+        t = np.eye(4) if camera.transform is None else _arr(camera.transform)
+        t = np.ascontiguousarray(t, dtype=np.float64)
+        counts = (C.c_uint64 * 4)()
+        rc = lib.orc_render(self._w, h, v, camera.field_of_view, _p(t), 0 if camera.transform is None else 1, depth,
+                            b, e, s, _p(out), nthreads, counts)
+        if rc != 0:
+            raise ValueError("oracle: camera transform is not invertible")
+        return out, list(counts)
+
+    def color_at(self, rays, depth=5):
+        r = _arr(rays).reshape(-1, 6)
+        out = np.empty((r.shape[0], 3))
+        lib.orc_color_at(self._w, _p(r), r.shape[0], depth, _p(out))
+        return out
+
+    def probe(self, rays):
+        r = _arr(rays).reshape(-1, 6)
+        out = np.empty((r.shape[0], 16))
+        lib.orc_probe(self._w, _p(r), r.shape[0], _p(out))
+        return out
+
+    def intersect(self, ray, cap=512):
+        r = _arr(ray, 6)
+        ts = np.empty(cap)
+        ids = (C.c_int * cap)()
+        n = lib.orc_intersect(self._w, _p(r), _p(ts), ids, cap)
+        n = min(n, cap)
+        return ts[:n].copy(), list(ids[:n])
+
+    def normal_at(self, node_id, point, u=0.0, v=0.0):
+        p = _arr(point, 3)
+        out = np.empty(3)
+        if lib.orc_normal_at(self._w, node_id, _p(p), u, v, _p(out)) != 0:
+            raise ValueError("bad node")
+        return out
+
+    def is_shadowed(self, point, light=0):
+        p = _arr(point, 3)
+        return lib.orc_is_shadowed(self._w, _p(p), light) == 1
+
+    def bounds(self, node_id):
+        out = np.empty(6)
+        lib.orc_bounds(self._w, node_id, _p(out))
+        return out[:3], out[3:]
+
+    def csg_includes_left(self, csg_id, node_id):
+        return lib.orc_csg_includes_left(self._w, csg_id, node_id)
+
+
+def ray_for_pixel(h, v, fov, transform, px, py):
+    out = np.empty(6)
+    t = np.eye(4) if transform is None else _arr(transform)
+    lib.orc_ray_for_pixel(h, v, fov, _p(np.ascontiguousarray(t)), 0 if transform is None else 1, px, py, _p(out))
+    return out
+
+
+def quantize(rgb):
+    src = _arr(rgb)
+    out = np.empty(src.size, dtype=np.uint8)
+    lib.orc_quantize(_p(src.reshape(-1)), src.size, out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return out.reshape(src.shape)
+
+
+def to_ppm(rgb):
+    src = _arr(rgb)
+    h, w = src.shape[0], src.shape[1]
+    n = lib.orc_to_ppm(_p(src), w, h, None, 0)
+    buf = C.create_string_buffer(n)
+    lib.orc_to_ppm(_p(src), w, h, buf, n)
+    return buf.raw
+
+
+def exercise_shading():
+    out = np.zeros((500, 500, 3))
+    lib.orc_exercise_shading(_p(out))
+    return out
+
+
+def matrix_inverse(m):
+    a = _arr(m)
+    out = np.empty((4, 4))
+    if lib.orc_matrix_inverse(_p(a), _p(out)) != 0:
+        raise ValueError("singular")
+    return out
+
+
+def matrix_mul(a, b):
+    out = np.empty((4, 4))
+    lib.orc_matrix_mul(_p(_arr(a)), _p(_arr(b)), _p(out))
+    return out
+
+
+def schlick(eye, normal, n1, n2):
+    return lib.orc_schlick(_p(_arr(eye, 3)), _p(_arr(normal, 3)), n1, n2)
+
+
+def max_threads():
+    return lib.orc_max_threads()

@@ -1,0 +1,556 @@
+// rt_hip.hip -- gfx950 kernels and the C ABI of include/rt_hip.h.
+//
+// Kernels (one lane = one pixel or one ray, FP64, no FMA contraction):
+//   render_kernel   Camera::render        (camera.rs:51-80)  8x8-pixel tile per wave
+//   color_at_kernel World::color_at       (world.rs:32-43)   batch of rays
+//   probe_kernel    prepare_computations  (intersection.rs:45-99) for the KATs
+//   quantize_kernel Canvas::scale_to_ppm_data (canvas.rs:85-90)
+// There is no CPU path in this library.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "rt_trace.h"
+
+using namespace rtd;
+
+// ============================================================== kernels ===
+namespace {
+
+struct RowMap {  // local row k -> image row (rt_hip_render_rows)
+    uint32_t part, n_parts, band_rows, n_local_rows;
+};
+
+template <bool STATS>
+__device__ void flush_stats(Ctx<STATS>& cx, RtStats* __restrict__ stats, unsigned* __restrict__ status) {
+    if (cx.status) atomicOr(status, cx.status);
+    if constexpr (STATS) {
+        unsigned long long* out = reinterpret_cast<unsigned long long*>(stats);
+#pragma unroll
+        for (int i = 0; i < ST_COUNT; ++i) {
+            unsigned v = cx.cnt[i];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if ((threadIdx.x & 63u) == 0u && v) atomicAdd(out + i, (unsigned long long)v);
+        }
+    }
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(256) void render_kernel(SceneDev S, RtCameraDesc cam, int depth, RowMap rows,
+                                                     double* __restrict__ out, RtStats* __restrict__ stats,
+                                                     unsigned* __restrict__ status) {
+    // 16x16 pixels per block, one 8x8 tile per wave: neighbouring pixels share a wave
+    const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const unsigned x = blockIdx.x * 16u + (wave & 1u) * 8u + (lane & 7u);
+    const unsigned k = blockIdx.y * 16u + (wave >> 1) * 8u + (lane >> 3);
+    Ctx<STATS> cx;
+    cx.status = 0;
+    if constexpr (STATS) {
+#pragma unroll
+        for (int i = 0; i < ST_COUNT; ++i) cx.cnt[i] = 0;
+    }
+    bool active = x < cam.hsize && k < rows.n_local_rows;
+    unsigned y = 0;
+    if (active) {
+        y = ((k / rows.band_rows) * rows.n_parts + rows.part) * rows.band_rows + k % rows.band_rows;
+        active = y < cam.vsize;
+    }
+    if (active) {
+        Scratch W;
+        Frame frames[RT_MAX_DEPTH + 1];
+        const Ray ray = ray_for_pixel(cam, x, y);
+        count(cx, ST_RAY_PRIMARY);
+        const V3 c = color_at(S, W, frames, ray, depth, cx);
+        double* o = out + ((size_t)k * cam.hsize + x) * 3u;
+        o[0] = c.x;
+        o[1] = c.y;
+        o[2] = c.z;
+    }
+    flush_stats(cx, stats, status);
+}
+
+__global__ __launch_bounds__(256) void color_at_kernel(SceneDev S, const double* __restrict__ rays, unsigned n,
+                                                       int depth, double* __restrict__ out,
+                                                       unsigned* __restrict__ status) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    Ctx<false> cx;
+    cx.status = 0;
+    if (i < n) {
+        Scratch W;
+        Frame frames[RT_MAX_DEPTH + 1];
+        const double* r = rays + (size_t)i * 6u;
+        const Ray ray{v3(r[0], r[1], r[2]), v3(r[3], r[4], r[5])};
+        const V3 c = color_at(S, W, frames, ray, depth, cx);
+        out[(size_t)i * 3u] = c.x;
+        out[(size_t)i * 3u + 1u] = c.y;
+        out[(size_t)i * 3u + 2u] = c.z;
+    }
+    flush_stats(cx, nullptr, status);
+}
+
+__global__ __launch_bounds__(256) void probe_kernel(SceneDev S, const double* __restrict__ rays, unsigned n,
+                                                    double* __restrict__ out, unsigned* __restrict__ status) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    Ctx<false> cx;
+    cx.status = 0;
+    if (i < n) {
+        Scratch W;
+        const double* r = rays + (size_t)i * 6u;
+        double* o = out + (size_t)i * 16u;
+        for (int k = 0; k < 16; ++k) o[k] = 0.0;
+        const Ray ray{v3(r[0], r[1], r[2]), v3(r[3], r[4], r[5])};
+        Best hit;
+        if (find_hit(S, W, ray, hit, cx)) {
+            Comps c;
+            prepare_computations(S, W, ray, hit, true, c, cx);
+            o[0] = 1.0, o[1] = hit.t, o[2] = (double)hit.idx, o[3] = c.n1, o[4] = c.n2, o[5] = c.inside ? 1.0 : 0.0;
+            o[6] = c.over_point.x, o[7] = c.over_point.y, o[8] = c.over_point.z;
+            o[9] = c.normal_v.x, o[10] = c.normal_v.y, o[11] = c.normal_v.z;
+            o[12] = c.reflect_v.x, o[13] = c.reflect_v.y, o[14] = c.reflect_v.z;
+            if (S.n_lights > 0u) {
+                const RtLight l = S.lights[0];
+                o[15] = is_shadowed(S, W, c.over_point, v3(l.position[0], l.position[1], l.position[2]), cx) ? 1.0 : 0.0;
+            }
+        }
+    }
+    flush_stats(cx, nullptr, status);
+}
+
+// Canvas::scale_to_ppm_data (canvas.rs:85-90)
+__global__ __launch_bounds__(256) void quantize_kernel(const double* __restrict__ rgb, unsigned long long n,
+                                                       uint8_t* __restrict__ out) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        double v = rgb[i] * 255.0;
+        uint8_t q = 0;
+        if (v == v) {
+            v = v < 0.0 ? 0.0 : (v > 255.0 ? 255.0 : v);
+            q = (uint8_t)round(v);  // half away from zero, like f64::round
+        }
+        out[i] = q;
+    }
+}
+
+// ================================================================ host ===
+thread_local std::string g_hip_error;
+std::mutex g_mutex;
+bool g_initialised = false;
+int g_device = -1;
+
+int hip_fail(hipError_t e, const char* what) {
+    g_hip_error = std::string(what) + ": " + hipGetErrorString(e);
+    return RT_ERR_HIP;
+}
+#define HIP_TRY(expr)                                      \
+    do {                                                   \
+        const hipError_t e_ = (expr);                      \
+        if (e_ != hipSuccess) return hip_fail(e_, #expr); \
+    } while (0)
+
+int ensure_device() {
+    if (g_initialised) return RT_OK;
+    int n = 0;
+    const hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        g_hip_error = e != hipSuccess ? std::string("hipGetDeviceCount: ") + hipGetErrorString(e) : "no HIP device";
+        return RT_ERR_NO_DEVICE;
+    }
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return RT_ERR_NO_DEVICE;
+    g_device = dev;
+    g_initialised = true;
+    return RT_OK;
+}
+
+template <class T>
+int upload(const T* src, size_t n, T** dst) {
+    *dst = nullptr;
+    const size_t bytes = (n ? n : 1) * sizeof(T);
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(dst), bytes));
+    if (n) HIP_TRY(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+    return RT_OK;
+}
+
+unsigned max_hits_of_kind(unsigned kind) {
+    switch (kind) {
+        case RT_SPHERE: case RT_CUBE: return 2;
+        case RT_PLANE: case RT_TRIANGLE: case RT_SMOOTH_TRIANGLE: return 1;
+        default: return 4;
+    }
+}
+
+// Everything the kernels assume about the tables is checked here, so that no index read
+// from them can leave its table and every traversal loop advances strictly.
+int validate(const RtSceneDesc& d, uint32_t* flags_out) {
+    auto need = [](uint32_t n, const void* p) { return n == 0 || p != nullptr; };
+    if (!need(d.n_shapes, d.shapes) || !need(d.n_conics, d.conics) || !need(d.n_triangles, d.triangles) ||
+        !need(d.n_groups, d.groups) || !need(d.n_csgs, d.csgs) || !need(d.n_lhit, d.lhit) ||
+        !need(d.n_materials, d.materials) || !need(d.n_patterns, d.patterns) || !need(d.n_lights, d.lights) ||
+        !need(d.n_bvh_nodes, d.bvh_nodes))
+        return RT_ERR_INVALID_ARG;
+    if (d.n_shapes > 0x3fffffffu || d.n_bvh_nodes > 0x3fffffffu) return RT_ERR_INVALID_SCENE;
+    uint32_t flags = 0;
+    // patterns: children come after their parent (no cycles); arithmetic mixtures nest <= RT_PATTERN_STACK
+    std::vector<int> pat_depth(d.n_patterns, 0);
+    for (uint32_t k = d.n_patterns; k-- > 0;) {
+        const RtPattern& p = d.patterns[k];
+        if (p.kind > RT_PAT_TEST) return RT_ERR_INVALID_SCENE;
+        int da = 0, db = 0;
+        const bool unary = p.kind == RT_PAT_PERTURB;
+        const bool binary = p.kind >= RT_PAT_BLEND && p.kind <= RT_PAT_CHECKER;
+        if (unary || binary) {
+            if (p.a <= (int32_t)k || p.a >= (int32_t)d.n_patterns) return RT_ERR_INVALID_SCENE;
+            da = pat_depth[p.a];
+        }
+        if (binary) {
+            if (p.b <= (int32_t)k || p.b >= (int32_t)d.n_patterns) return RT_ERR_INVALID_SCENE;
+            db = pat_depth[p.b];
+        }
+        const bool arithmetic =
+            p.kind == RT_PAT_BLEND || p.kind == RT_PAT_GRADIENT || p.kind == RT_PAT_RADIAL_GRADIENT;
+        pat_depth[k] = (da > db ? da : db) + (arithmetic ? 1 : 0);
+        if (pat_depth[k] > RT_PATTERN_STACK) return RT_ERR_NEST_TOO_DEEP;
+    }
+    for (uint32_t k = 0; k < d.n_materials; ++k)
+        if (d.materials[k].pattern < -1 || d.materials[k].pattern >= (int32_t)d.n_patterns) return RT_ERR_INVALID_SCENE;
+    // shapes: depth-first pre-order with consistent parent / depth / skip
+    std::vector<uint32_t> open;  // enclosing compounds
+    std::vector<uint32_t> max_hits(d.n_shapes, 0);
+    for (uint32_t i = 0; i < d.n_shapes; ++i) {
+        const RtShape& s = d.shapes[i];
+        while (!open.empty() && d.shapes[open.back()].skip <= i) open.pop_back();
+        const int32_t parent = open.empty() ? -1 : (int32_t)open.back();
+        if (s.parent != parent || s.depth != open.size()) return RT_ERR_INVALID_SCENE;
+        if (s.skip <= i || s.skip > d.n_shapes) return RT_ERR_INVALID_SCENE;
+        if (parent >= 0 && s.skip > d.shapes[parent].skip) return RT_ERR_INVALID_SCENE;
+        const unsigned kind = RT_KIND(s.kind_flags);
+        if (kind > RT_CSG) return RT_ERR_INVALID_SCENE;
+        if (kind <= RT_SMOOTH_TRIANGLE) {
+            if (s.skip != i + 1 || s.material >= d.n_materials) return RT_ERR_INVALID_SCENE;
+            if (s.depth > RT_MAX_NEST) return RT_ERR_NEST_TOO_DEEP;
+            if ((kind == RT_CYLINDER || kind == RT_CONE) && s.param >= d.n_conics) return RT_ERR_INVALID_SCENE;
+            if ((kind == RT_TRIANGLE || kind == RT_SMOOTH_TRIANGLE) && s.param >= d.n_triangles)
+                return RT_ERR_INVALID_SCENE;
+            if (!(s.kind_flags & RT_FLAG_HAS_SHADOW)) flags |= RT_SCENE_HAS_SHADOWLESS;
+            max_hits[i] = max_hits_of_kind(kind);
+        } else {
+            if (s.depth >= RT_MAX_NEST) return RT_ERR_NEST_TOO_DEEP;
+            if (kind == RT_GROUP) {
+                if (s.param >= d.n_groups) return RT_ERR_INVALID_SCENE;
+                const RtGroup& g = d.groups[s.param];
+                if (g.bvh_root < -1 || g.bvh_root >= (int32_t)d.n_bvh_nodes) return RT_ERR_INVALID_SCENE;
+                if ((g.n_children == 0) != (s.skip == i + 1)) return RT_ERR_INVALID_SCENE;
+            } else {
+                if (s.param >= d.n_csgs) return RT_ERR_INVALID_SCENE;
+                const RtCsg& c = d.csgs[s.param];
+                const unsigned op = (s.kind_flags >> RT_FLAG_CSG_OP_SHIFT) & 3u;
+                if (c.op > 2 || c.op != op) return RT_ERR_INVALID_SCENE;
+                // exactly two children: left = i+1, right = left.skip, right.skip == skip
+                if (i + 1 >= d.n_shapes || i + 1 >= s.skip) return RT_ERR_INVALID_SCENE;
+                const uint32_t right = d.shapes[i + 1].skip;
+                if (right <= i + 1 || right >= s.skip || d.shapes[right].skip != s.skip) return RT_ERR_INVALID_SCENE;
+                if ((uint64_t)c.lhit_offset + (s.skip - i - 1) > d.n_lhit) return RT_ERR_INVALID_SCENE;
+            }
+            open.push_back(i);
+        }
+    }
+    // a CSG subtree's list must fit the per-lane list whatever the ray does
+    for (uint32_t i = d.n_shapes; i-- > 0;) {
+        const RtShape& s = d.shapes[i];
+        if (RT_KIND(s.kind_flags) > RT_SMOOTH_TRIANGLE) {
+            uint64_t sum = 0;
+            for (uint32_t c = i + 1; c < s.skip; c = d.shapes[c].skip) sum += max_hits[c];
+            max_hits[i] = (uint32_t)(sum > 0x7fffffffu ? 0x7fffffffu : sum);
+            if (RT_KIND(s.kind_flags) == RT_CSG && sum > RT_LIST_CAP) return RT_ERR_LIST_BOUND;
+        }
+    }
+    // acceleration nodes: links only go forward (every walk terminates), leaves name real shapes
+    for (uint32_t k = 0; k < d.n_bvh_nodes; ++k) {
+        const RtBvhNode& nd = d.bvh_nodes[k];
+        if (nd.miss != -1 && (nd.miss <= (int32_t)k || nd.miss >= (int32_t)d.n_bvh_nodes)) return RT_ERR_INVALID_SCENE;
+        if (nd.shape < -1 || nd.shape >= (int32_t)d.n_shapes) return RT_ERR_INVALID_SCENE;
+        if (nd.shape < 0 && k + 1 >= d.n_bvh_nodes) return RT_ERR_INVALID_SCENE;  // inner node needs a successor
+    }
+    if (d.world_bvh_root < -1 || d.world_bvh_root >= (int32_t)d.n_bvh_nodes) return RT_ERR_INVALID_SCENE;
+    *flags_out = flags;
+    return RT_OK;
+}
+
+}  // namespace
+
+struct RtScene {
+    SceneDev dev;
+    unsigned* d_status;
+    int device;
+    std::vector<void*> allocations;
+};
+
+namespace {
+
+int check_camera(const RtCameraDesc* cam, uint32_t depth) {
+    if (!cam || cam->hsize == 0 || cam->vsize == 0) return RT_ERR_INVALID_ARG;
+    if (depth > RT_MAX_DEPTH) return RT_ERR_DEPTH;
+    return RT_OK;
+}
+
+int status_to_error(unsigned flags) {
+    if (flags & RT_STATUS_LIST_OVERFLOW) return RT_ERR_LIST_OVERFLOW;
+    if (flags & RT_STATUS_NAN_T) return RT_ERR_NAN_T;
+    return RT_OK;
+}
+
+int read_status(const RtScene* scene, hipStream_t stream) {
+    unsigned flags = 0;
+    HIP_TRY(hipMemcpyAsync(&flags, scene->d_status, sizeof flags, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (flags) HIP_TRY(hipMemsetAsync(scene->d_status, 0, sizeof(unsigned), stream));
+    return status_to_error(flags);
+}
+
+int launch_render(const RtScene* scene, const RtCameraDesc* cam, uint32_t depth, const RowMap& rows, double* d_out,
+                  hipStream_t stream, RtStats* d_stats) {
+    const dim3 block(256);
+    const dim3 grid((cam->hsize + 15u) / 16u, (rows.n_local_rows + 15u) / 16u);
+    if (grid.y > 65535u * 16u) return RT_ERR_INVALID_ARG;
+    if (d_stats)
+        hipLaunchKernelGGL(render_kernel<true>, grid, block, 0, stream, scene->dev, *cam, (int)depth, rows, d_out, d_stats,
+                           scene->d_status);
+    else
+        hipLaunchKernelGGL(render_kernel<false>, grid, block, 0, stream, scene->dev, *cam, (int)depth, rows, d_out,
+                           (RtStats*)nullptr, scene->d_status);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+}  // namespace
+
+// =============================================================== C ABI ===
+extern "C" {
+
+int rt_hip_init(int device) {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    int n = 0;
+    const hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        g_hip_error = e != hipSuccess ? std::string("hipGetDeviceCount: ") + hipGetErrorString(e) : "no HIP device";
+        return RT_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= n) return RT_ERR_INVALID_ARG;
+    HIP_TRY(hipSetDevice(device));
+    g_device = device;
+    g_initialised = true;
+    return RT_OK;
+}
+
+void rt_hip_shutdown(void) {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    g_initialised = false;
+    g_device = -1;
+}
+
+const char* rt_hip_strerror(int code) {
+    switch (code) {
+        case RT_OK: return "ok";
+        case RT_ERR_NO_DEVICE: return "no HIP device available (this library has no CPU path)";
+        case RT_ERR_HIP: return "HIP runtime error";
+        case RT_ERR_INVALID_SCENE: return "malformed scene tables";
+        case RT_ERR_NEST_TOO_DEEP: return "compound or pattern nesting too deep";
+        case RT_ERR_LIST_BOUND: return "a CSG subtree can yield more intersections than the per-lane list holds";
+        case RT_ERR_LIST_OVERFLOW: return "per-lane intersection list overflowed";
+        case RT_ERR_NAN_T: return "a NaN intersection distance was dropped (the reference panics: t is not NaN)";
+        case RT_ERR_INVALID_ARG: return "invalid argument";
+        case RT_ERR_DEPTH: return "recursion budget above RT_MAX_DEPTH";
+        default: return "unknown error";
+    }
+}
+
+const char* rt_hip_last_hip_error(void) { return g_hip_error.c_str(); }
+
+int rt_hip_scene_create(const RtSceneDesc* desc, RtScene** out) {
+    if (!desc || !out) return RT_ERR_INVALID_ARG;
+    *out = nullptr;
+    uint32_t flags = 0;
+    const int v = validate(*desc, &flags);
+    if (v != RT_OK) return v;
+    {
+        std::lock_guard<std::mutex> lock(g_mutex);
+        const int rc = ensure_device();
+        if (rc != RT_OK) return rc;
+    }
+    RtScene* s = new RtScene();
+    std::memset(&s->dev, 0, sizeof s->dev);
+    s->d_status = nullptr;
+    s->device = g_device;
+    int rc = RT_OK;
+    auto up = [&](auto* src, size_t n, auto** dst) {
+        if (rc != RT_OK) return;
+        rc = upload(src, n, dst);
+        if (*dst) s->allocations.push_back((void*)*dst);
+    };
+    RtShape* shapes; RtConic* conics; RtTriangle* tris; RtGroup* groups; RtCsg* csgs; uint8_t* lhit;
+    RtMaterial* mats; RtPattern* pats; RtLight* lights; RtBvhNode* bvh;
+    shapes = nullptr, conics = nullptr, tris = nullptr, groups = nullptr, csgs = nullptr, lhit = nullptr;
+    mats = nullptr, pats = nullptr, lights = nullptr, bvh = nullptr;
+    up(desc->shapes, desc->n_shapes, &shapes);
+    up(desc->conics, desc->n_conics, &conics);
+    up(desc->triangles, desc->n_triangles, &tris);
+    up(desc->groups, desc->n_groups, &groups);
+    up(desc->csgs, desc->n_csgs, &csgs);
+    up(desc->lhit, desc->n_lhit, &lhit);
+    up(desc->materials, desc->n_materials, &mats);
+    up(desc->patterns, desc->n_patterns, &pats);
+    up(desc->lights, desc->n_lights, &lights);
+    up(desc->bvh_nodes, desc->n_bvh_nodes, &bvh);
+    if (rc == RT_OK) {
+        const hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->d_status), sizeof(unsigned));
+        if (e != hipSuccess) rc = hip_fail(e, "hipMalloc(status)");
+        else {
+            s->allocations.push_back(s->d_status);
+            const hipError_t e2 = hipMemset(s->d_status, 0, sizeof(unsigned));
+            if (e2 != hipSuccess) rc = hip_fail(e2, "hipMemset(status)");
+        }
+    }
+    if (rc != RT_OK) {
+        rt_hip_scene_destroy(s);
+        return rc;
+    }
+    s->dev.shapes = shapes, s->dev.conics = conics, s->dev.tris = tris, s->dev.groups = groups, s->dev.csgs = csgs;
+    s->dev.lhit = lhit, s->dev.mats = mats, s->dev.pats = pats, s->dev.lights = lights, s->dev.bvh = bvh;
+    s->dev.n_shapes = desc->n_shapes;
+    s->dev.n_lights = desc->n_lights;
+    s->dev.world_bvh_root = desc->world_bvh_root;
+    s->dev.flags = flags;
+    *out = s;
+    return RT_OK;
+}
+
+void rt_hip_scene_destroy(RtScene* scene) {
+    if (!scene) return;
+    for (void* p : scene->allocations) (void)hipFree(p);
+    delete scene;
+}
+
+int rt_hip_scene_status(const RtScene* scene, void* hip_stream) {
+    if (!scene) return RT_ERR_INVALID_ARG;
+    return read_status(scene, static_cast<hipStream_t>(hip_stream));
+}
+
+int rt_hip_render_rows(const RtScene* scene, const RtCameraDesc* cam, uint32_t depth, uint32_t part, uint32_t n_parts,
+                       uint32_t band_rows, uint32_t n_local_rows, double* d_out_rgb, void* hip_stream,
+                       RtStats* d_stats) {
+    if (!scene || !d_out_rgb || n_parts == 0 || part >= n_parts || band_rows == 0) return RT_ERR_INVALID_ARG;
+    const int rc = check_camera(cam, depth);
+    if (rc != RT_OK) return rc;
+    if (n_local_rows == 0) return RT_OK;
+    const RowMap rows{part, n_parts, band_rows, n_local_rows};
+    return launch_render(scene, cam, depth, rows, d_out_rgb, static_cast<hipStream_t>(hip_stream), d_stats);
+}
+
+int rt_hip_render(const RtSceneDesc* desc, const RtCameraDesc* cam, uint32_t depth, double* out_rgb, RtStats* stats) {
+    if (!out_rgb) return RT_ERR_INVALID_ARG;
+    int rc = check_camera(cam, depth);
+    if (rc != RT_OK) return rc;
+    RtScene* scene = nullptr;
+    rc = rt_hip_scene_create(desc, &scene);
+    if (rc != RT_OK) return rc;
+    const size_t n_values = (size_t)cam->hsize * cam->vsize * 3u;
+    double* d_out = nullptr;
+    RtStats* d_stats = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    auto body = [&]() -> int {
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_out), n_values * sizeof(double)));
+        if (stats) {
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_stats), sizeof(RtStats)));
+            HIP_TRY(hipMemset(d_stats, 0, sizeof(RtStats)));
+            HIP_TRY(hipEventCreate(&e0));
+            HIP_TRY(hipEventCreate(&e1));
+            HIP_TRY(hipEventRecord(e0, nullptr));
+        }
+        const RowMap rows{0u, 1u, cam->vsize, cam->vsize};
+        const int lrc = launch_render(scene, cam, depth, rows, d_out, nullptr, d_stats);
+        if (lrc != RT_OK) return lrc;
+        if (stats) HIP_TRY(hipEventRecord(e1, nullptr));
+        HIP_TRY(hipMemcpy(out_rgb, d_out, n_values * sizeof(double), hipMemcpyDeviceToHost));
+        const int src = read_status(scene, nullptr);
+        if (stats) {
+            HIP_TRY(hipMemcpy(stats, d_stats, sizeof(RtStats), hipMemcpyDeviceToHost));
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+            stats->kernel_ms = ms;
+            if (src != RT_OK) stats->status_flags |= 1ull << (unsigned)(-src);
+        }
+        return src;
+    };
+    rc = body();
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (d_out) (void)hipFree(d_out);
+    if (d_stats) (void)hipFree(d_stats);
+    rt_hip_scene_destroy(scene);
+    return rc;
+}
+
+int rt_hip_color_at(const RtScene* scene, const double* rays, uint32_t n, uint32_t depth, double* out_rgb) {
+    if (!scene || (n && (!rays || !out_rgb))) return RT_ERR_INVALID_ARG;
+    if (depth > RT_MAX_DEPTH) return RT_ERR_DEPTH;
+    if (n == 0) return RT_OK;
+    double *d_rays = nullptr, *d_out = nullptr;
+    auto body = [&]() -> int {
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_rays), (size_t)n * 6u * sizeof(double)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_out), (size_t)n * 3u * sizeof(double)));
+        HIP_TRY(hipMemcpy(d_rays, rays, (size_t)n * 6u * sizeof(double), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(color_at_kernel, dim3((n + 255u) / 256u), dim3(256), 0, nullptr, scene->dev, d_rays, n,
+                           (int)depth, d_out, scene->d_status);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpy(out_rgb, d_out, (size_t)n * 3u * sizeof(double), hipMemcpyDeviceToHost));
+        return read_status(scene, nullptr);
+    };
+    const int rc = body();
+    if (d_rays) (void)hipFree(d_rays);
+    if (d_out) (void)hipFree(d_out);
+    return rc;
+}
+
+int rt_hip_probe(const RtScene* scene, const double* rays, uint32_t n, double* out) {
+    if (!scene || (n && (!rays || !out))) return RT_ERR_INVALID_ARG;
+    if (n == 0) return RT_OK;
+    double *d_rays = nullptr, *d_out = nullptr;
+    auto body = [&]() -> int {
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_rays), (size_t)n * 6u * sizeof(double)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_out), (size_t)n * 16u * sizeof(double)));
+        HIP_TRY(hipMemcpy(d_rays, rays, (size_t)n * 6u * sizeof(double), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(probe_kernel, dim3((n + 255u) / 256u), dim3(256), 0, nullptr, scene->dev, d_rays, n, d_out,
+                           scene->d_status);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpy(out, d_out, (size_t)n * 16u * sizeof(double), hipMemcpyDeviceToHost));
+        return read_status(scene, nullptr);
+    };
+    const int rc = body();
+    if (d_rays) (void)hipFree(d_rays);
+    if (d_out) (void)hipFree(d_out);
+    return rc;
+}
+
+int rt_hip_quantize(const double* d_rgb, uint64_t n_values, uint8_t* d_out, void* hip_stream) {
+    if (n_values && (!d_rgb || !d_out)) return RT_ERR_INVALID_ARG;
+    if (n_values == 0) return RT_OK;
+    {
+        std::lock_guard<std::mutex> lock(g_mutex);
+        const int rc = ensure_device();
+        if (rc != RT_OK) return rc;
+    }
+    uint64_t blocks = (n_values + 255u) / 256u;
+    if (blocks > 8192u) blocks = 8192u;
+    hipLaunchKernelGGL(quantize_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(hip_stream), d_rgb,
+                       (unsigned long long)n_values, d_out);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+}  // extern "C"

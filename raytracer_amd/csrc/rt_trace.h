@@ -1,0 +1,727 @@
+// rt_trace.h -- the per-ray integrator on the flat tables of include/rt_hip.h:
+// world traversal (closest hit / shadow any-hit), the sorted-hit-list evaluator
+// used for CSG subtrees and the containers (n1/n2) pass, prepare_computations,
+// lighting and the reflect/refract recursion unrolled into an explicit per-lane
+// frame stack.  One lane traces one pixel/ray.
+//
+// How the reference's set semantics are kept without building its BTreeSet for
+// every ray:
+//   * closest hit = first t >= 0 of the merged sorted set.  Outside CSG nodes a
+//     merge only reorders and, on a bit-equal t, keeps the entry of the shape
+//     that comes LATER in traversal order (Q1).  So the hit is
+//     argmin (t, then larger depth-first index) over each primitive's own
+//     collected hits (Q2), which streams with no list at all;
+//   * a CSG node needs its operands' sorted lists (filter toggles, post-filter
+//     dedupe), so its subtree is evaluated by `list_eval` into a per-lane list
+//     and the survivors are fed to the same reduction;
+//   * n1/n2 need every entry up to the hit in sorted order: `list_eval` over the
+//     whole world, run only for hits whose material is transparent (Q4);
+//   * shadows: "first has_shadow entry with t >= 0 lies before the light"
+//     == "some surviving has_shadow entry has 0 <= t < distance".  An entry only
+//     fails to survive a merge when a later shape has the bit-equal t; if that
+//     shape casts a shadow too the answer is unchanged, so with no shadowless
+//     primitive in the scene any-hit with early out is exact.  Scenes that do
+//     contain `with_shadow(false)` primitives evaluate the full list instead.
+#pragma once
+#include "rt_device.h"
+
+namespace rtd {
+
+#define RT_STACK (RT_MAX_NEST + 2)
+#define RT_CONTAINERS_CAP 24
+#define RT_SCENE_HAS_SHADOWLESS 1u
+
+struct SceneDev {
+    const RtShape* __restrict__ shapes;
+    const RtConic* __restrict__ conics;
+    const RtTriangle* __restrict__ tris;
+    const RtGroup* __restrict__ groups;
+    const RtCsg* __restrict__ csgs;
+    const uint8_t* __restrict__ lhit;
+    const RtMaterial* __restrict__ mats;
+    const RtPattern* __restrict__ pats;
+    const RtLight* __restrict__ lights;
+    const RtBvhNode* __restrict__ bvh;
+    uint32_t n_shapes, n_lights;
+    int32_t world_bvh_root;
+    uint32_t flags;
+};
+
+// ---- event counters (RtStats order) ------------------------------------------
+enum {
+    ST_RAY_PRIMARY = 0, ST_RAY_SHADOW, ST_RAY_REFLECT, ST_RAY_REFRACT,
+    ST_PRIM0,  // .. ST_PRIM0 + 6
+    ST_RAY_XFORM = ST_PRIM0 + 7, ST_GATES, ST_BVH_BOX, ST_HITS_SHADED, ST_NORMAL_LEVELS, ST_LIGHTINGS, ST_POW,
+    ST_PATTERN_NODES, ST_CONTAINER_PASSES, ST_LIST_ENTRIES, ST_SCHLICK, ST_COUNT
+};
+#define RT_STATUS_LIST_OVERFLOW (1u << 6)  // 1 << -RT_ERR_LIST_OVERFLOW
+#define RT_STATUS_NAN_T (1u << 7)          // 1 << -RT_ERR_NAN_T
+
+template <bool STATS>
+struct Ctx {
+    unsigned cnt[STATS ? ST_COUNT : 1];
+    unsigned status;
+};
+template <bool STATS>
+RT_DEV void count(Ctx<STATS>& cx, int what, unsigned n = 1) {
+    if constexpr (STATS) cx.cnt[what] += n;
+}
+
+// Per-lane working memory (private segment; lanes of a wave interleave, so equal
+// indices coalesce).  Levels are absolute nesting depths, shared by the
+// streaming traversal and the list evaluator it calls for CSG nodes.
+struct Scratch {
+    Ray rays[RT_STACK];   // ray in the local space of the compound open at each level
+    int cur[RT_STACK];    // streaming traversal: saved cursor
+    int end[RT_STACK];    //   linear scan: end index; -2: the level walks a BVH
+    int fnode[RT_STACK];  // list evaluator: compound open at each level
+    int fbase[RT_STACK];  //   start of its accumulated list
+    double lt[RT_LIST_CAP];
+    uint32_t lid[RT_LIST_CAP];
+};
+
+// ---- one primitive's own hit set ----------------------------------------------
+// `.collect::<BTreeSet<_>>()` of primitive.rs:227-230 (Q2) on at most four values,
+// with static indexing only: sorted t[0..n) plus a keep mask (bit i clear = entry i
+// was dropped because it is ~equal to entry i+1).
+struct PrimHits {
+    double t[4];
+    int n;
+    unsigned keep;
+};
+RT_DEV void cswap(double& a, double& b) {
+    const double lo = a <= b ? a : b;
+    const double hi = a <= b ? b : a;
+    a = lo;
+    b = hi;
+}
+RT_DEV void finish_hits(PrimHits& h, unsigned& status) {
+    const double INF = __builtin_inf();
+    // NaN distances: the reference panics (intersection.rs:119); drop and flag
+    int m = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const bool valid = i < h.n && h.t[i] == h.t[i];
+        if (i < h.n && !valid) status |= RT_STATUS_NAN_T;
+        h.t[i] = valid ? h.t[i] : INF;
+        m += valid ? 1 : 0;
+    }
+    if (h.n > 1) {
+        cswap(h.t[0], h.t[1]);
+        cswap(h.t[2], h.t[3]);
+        cswap(h.t[0], h.t[2]);
+        cswap(h.t[1], h.t[3]);
+        cswap(h.t[1], h.t[2]);
+    }
+    h.n = m;
+    unsigned keep = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const bool drop = (i + 1 < m) && t_eq(h.t[i], h.t[i + 1 < 4 ? i + 1 : 3]);
+        if (i < m && !drop) keep |= 1u << i;
+    }
+    h.keep = keep;
+}
+
+template <bool STATS>
+RT_DEV void prim_intersect(const SceneDev& S, const RtShape* __restrict__ sh, unsigned kf, const Ray& parent_ray,
+                           PrimHits& h, Ctx<STATS>& cx) {
+    const Ray r = transform_ray(sh->inv, parent_ray);  // shape.rs:28-32
+    const unsigned kind = RT_KIND(kf);
+    count(cx, ST_RAY_XFORM);
+    count(cx, ST_PRIM0 + (int)kind);
+    h.n = 0;
+    if (kind == RT_SPHERE) {
+        h.n = sphere_intersect(r, h.t);
+    } else if (kind == RT_PLANE) {
+        h.n = plane_intersect(r, h.t);
+    } else if (kind == RT_CUBE) {
+        h.n = cube_intersect(r, h.t);
+    } else if (kind == RT_CYLINDER || kind == RT_CONE) {
+        const RtConic c = S.conics[sh->param];
+        const bool closed = (kf & RT_FLAG_CLOSED) != 0;
+        h.n = kind == RT_CYLINDER ? cylinder_intersect(r, c.minimum, c.maximum, closed, h.t)
+                                  : cone_intersect(r, c.minimum, c.maximum, closed, h.t);
+    } else {
+        double u, v;
+        h.n = triangle_intersect(S.tris + sh->param, r, h.t, u, v);
+    }
+    finish_hits(h, cx.status);
+}
+
+// ---- sorted hit list (stands for BTreeSet<Intersection>) -----------------------
+// BTreeSet::append of one element (Q1): on a bit-equal t the new entry replaces the old.
+RT_DEV int list_insert(Scratch& W, int base, int top, double t, uint32_t id, unsigned& status) {
+    int pos = top;
+    while (pos > base && W.lt[pos - 1] > t) --pos;
+    if (pos > base && W.lt[pos - 1] == t) {
+        W.lid[pos - 1] = id;
+        return top;
+    }
+    if (top >= RT_LIST_CAP) {
+        status |= RT_STATUS_LIST_OVERFLOW;
+        return top;
+    }
+    for (int j = top; j > pos; --j) {
+        W.lt[j] = W.lt[j - 1];
+        W.lid[j] = W.lid[j - 1];
+    }
+    W.lt[pos] = t;
+    W.lid[pos] = id;
+    return top + 1;
+}
+// self.append(other) for two adjacent runs [a,b) and [b,c): returns the new top.
+RT_DEV int list_merge(Scratch& W, int a, int b, int c, unsigned& status) {
+    if (a == b) return c;
+    int top = b;
+    for (int r = b; r < c; ++r) {
+        const double t = W.lt[r];
+        const uint32_t id = W.lid[r];
+        top = list_insert(W, a, top, t, id, status);
+    }
+    return top;
+}
+// Operation::filter_intersections (compound.rs:142-168) in place on [b, top), then the
+// `.collect()` dedupe (Q2).  `g` is the CSG node's shape index.
+RT_DEV int csg_filter(const SceneDev& S, Scratch& W, int b, int top, int g, unsigned op, unsigned lhit_offset) {
+    bool in_l = false, in_r = false;
+    int k = b;
+    for (int j = b; j < top; ++j) {
+        const uint32_t id = W.lid[j];
+        const bool l_hit = S.lhit[lhit_offset + (id - (uint32_t)g - 1u)] != 0;
+        bool allowed;  // compound.rs:175-181
+        if (op == 0u)
+            allowed = (l_hit && !in_r) || (!l_hit && !in_l);
+        else if (op == 1u)
+            allowed = (l_hit && in_r) || (!l_hit && in_l);
+        else
+            allowed = (l_hit && !in_r) || (!l_hit && in_l);
+        if (l_hit)
+            in_l = !in_l;
+        else
+            in_r = !in_r;
+        if (allowed) {
+            W.lt[k] = W.lt[j];
+            W.lid[k] = id;
+            ++k;
+        }
+    }
+    int m = b;
+    for (int j = b; j < k; ++j) {
+        if (j + 1 < k && t_eq(W.lt[j], W.lt[j + 1])) continue;
+        W.lt[m] = W.lt[j];
+        W.lid[m] = W.lid[j];
+        ++m;
+    }
+    return m;
+}
+
+// Sorted intersections of the sibling shapes [begin, end) -- all at nesting level
+// `level0`, whose ray is W.rays[level0] -- appended at W.lt/lid[base0 ..).  Entries with
+// t > bound are not recorded (callers pass a bound that leaves a margin wider than every
+// dedupe window between the entries they read and the cut).  Returns the new top.
+// Shape::intersect / Compound::local_intersect / World::intersections
+// (shape.rs:28-32, compound.rs:87-117, world.rs:45-53).
+template <bool STATS>
+RT_DEV int list_eval(const SceneDev& S, Scratch& W, int begin, int end, int level0, int base0, double bound,
+                     Ctx<STATS>& cx) {
+    int level = level0;
+    int top = base0;
+    int base = base0;  // start of the list of the compound open at `level`
+    int i = begin;
+    for (;;) {
+        while (level > level0 && i >= (int)S.shapes[W.fnode[level]].skip) {  // subtree finished
+            const int g = W.fnode[level];
+            const RtShape* __restrict__ gs = S.shapes + g;
+            if (RT_KIND(gs->kind_flags) == RT_CSG) {
+                const RtCsg c = S.csgs[gs->param];
+                top = csg_filter(S, W, base, top, g, c.op, c.lhit_offset);
+            }
+            const int parent_base = level - 1 > level0 ? W.fbase[level - 1] : base0;
+            top = list_merge(W, parent_base, base, top, cx.status);
+            base = parent_base;
+            --level;
+        }
+        if (i >= end) break;
+        const RtShape* __restrict__ sh = S.shapes + i;
+        const unsigned kf = sh->kind_flags;
+        const unsigned kind = RT_KIND(kf);
+        if (kind <= RT_SMOOTH_TRIANGLE) {
+            PrimHits h;
+            prim_intersect(S, sh, kf, W.rays[level], h, cx);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (((h.keep >> k) & 1u) && h.t[k] <= bound) {
+                    top = list_insert(W, base, top, h.t[k], (uint32_t)i, cx.status);
+                    count(cx, ST_LIST_ENTRIES);
+                }
+            }
+            ++i;
+            continue;
+        }
+        const Ray lr = transform_ray(sh->inv, W.rays[level]);
+        count(cx, ST_RAY_XFORM);
+        if (kind == RT_GROUP) {
+            const RtGroup* __restrict__ g = S.groups + sh->param;
+            count(cx, ST_GATES);
+            if (g->n_children == 0u || !box_intersects(g->bmin, g->bmax, lr)) {  // compound.rs:93-95
+                i = (int)sh->skip;
+                continue;
+            }
+        }
+        ++level;
+        W.rays[level] = lr;
+        W.fnode[level] = i;
+        W.fbase[level] = top;
+        base = top;
+        ++i;
+    }
+    return top;
+}
+
+// ---- streaming world traversal ---------------------------------------------------
+struct Best {
+    double t;
+    int idx;
+};
+RT_DEV void offer(Best& best, double t, int idx) {  // first t >= 0; bit-equal t: later shape wins (Q1, Q3)
+    if (t >= 0.0 && (t < best.t || (t == best.t && idx > best.idx))) {
+        best.t = t;
+        best.idx = idx;
+    }
+}
+
+// Acceleration-only slab test against a padded box: can the ray meet it for some t in
+// [0, t_far]?  Never used for a decision the reference makes.
+RT_DEV bool accel_box(const RtBvhNode* __restrict__ nd, const V3& o, const V3& inv_d, double t_far) {
+    const double ax = (nd->bmin[0] - o.x) * inv_d.x, bx = (nd->bmax[0] - o.x) * inv_d.x;
+    const double ay = (nd->bmin[1] - o.y) * inv_d.y, by = (nd->bmax[1] - o.y) * inv_d.y;
+    const double az = (nd->bmin[2] - o.z) * inv_d.z, bz = (nd->bmax[2] - o.z) * inv_d.z;
+    const double t0 = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmin(az, bz));
+    const double t1 = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmax(az, bz));
+    // the reciprocal costs an ulp or two; boxes are padded far wider than that
+    return !(t0 > t1) && !(t1 < 0.0) && !(t0 > t_far);
+}
+
+// SHADOW == false: closest hit into `best`.  SHADOW == true: returns true as soon as a
+// shadow-casting primitive is met at 0 <= t < limit (world.rs:85-96).
+template <bool SHADOW, bool STATS>
+RT_DEV bool traverse(const SceneDev& S, Scratch& W, const Ray& world_ray, double limit, Best& best, Ctx<STATS>& cx) {
+    int level = 0;
+    Ray ray = world_ray;
+    bool bvh = S.world_bvh_root >= 0;
+    int cur = bvh ? S.world_bvh_root : 0;
+    int end = (int)S.n_shapes;
+    V3 inv_d = v3(1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z);
+    for (;;) {
+        int s = -1;
+        if (bvh) {
+            if (cur >= 0) {
+                const RtBvhNode* __restrict__ nd = S.bvh + cur;
+                count(cx, ST_BVH_BOX);
+                const double t_far = SHADOW ? limit : best.t;
+                if (!accel_box(nd, ray.o, inv_d, t_far)) {
+                    cur = nd->miss;
+                    continue;
+                }
+                const int leaf = nd->shape;
+                if (leaf < 0) {
+                    ++cur;
+                    continue;
+                }
+                s = leaf;
+                cur = nd->miss;
+            }
+        } else if (cur < end) {
+            s = cur;
+            cur = (int)S.shapes[s].skip;
+        }
+        if (s < 0) {  // this level is exhausted
+            if (level == 0) break;
+            --level;
+            ray = W.rays[level];
+            cur = W.cur[level];
+            end = W.end[level];
+            bvh = end == -2;
+            if (bvh) inv_d = v3(1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z);
+            continue;
+        }
+        const RtShape* __restrict__ sh = S.shapes + s;
+        const unsigned kf = sh->kind_flags;
+        const unsigned kind = RT_KIND(kf);
+        if (kind <= RT_SMOOTH_TRIANGLE) {
+            if (SHADOW && !(kf & RT_FLAG_HAS_SHADOW)) continue;
+            PrimHits h;
+            prim_intersect(S, sh, kf, ray, h, cx);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if ((h.keep >> k) & 1u) {
+                    if (SHADOW) {
+                        if (h.t[k] >= 0.0 && h.t[k] < limit) return true;
+                    } else {
+                        offer(best, h.t[k], s);
+                    }
+                }
+            }
+            continue;
+        }
+        if (kind == RT_GROUP) {
+            const Ray lr = transform_ray(sh->inv, ray);
+            const RtGroup* __restrict__ g = S.groups + sh->param;
+            count(cx, ST_RAY_XFORM);
+            count(cx, ST_GATES);
+            if (g->n_children == 0u || !box_intersects(g->bmin, g->bmax, lr)) continue;  // compound.rs:93-95
+            W.rays[level] = ray;
+            W.cur[level] = cur;
+            W.end[level] = bvh ? -2 : end;
+            ++level;
+            ray = lr;
+            const int root = g->bvh_root;
+            bvh = root >= 0;
+            if (bvh) {
+                cur = root;
+                inv_d = v3(1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z);
+            } else {
+                cur = s + 1;
+                end = (int)sh->skip;
+            }
+            continue;
+        }
+        // CSG: materialise the subtree's filtered list, then reduce its survivors
+        W.rays[level] = ray;
+        const int n = list_eval(S, W, s, (int)sh->skip, level, 0, __builtin_inf(), cx);
+        for (int j = 0; j < n; ++j) {
+            const double t = W.lt[j];
+            const int id = (int)W.lid[j];
+            if (SHADOW) {
+                if ((S.shapes[id].kind_flags & RT_FLAG_HAS_SHADOW) && t >= 0.0 && t < limit) return true;
+            } else {
+                offer(best, t, id);
+            }
+        }
+    }
+    return false;
+}
+
+// ---- object space / normals (primitive.rs:153-192) -----------------------------------
+RT_DEV int ancestor_chain(const SceneDev& S, int parent, int* chain) {  // innermost first == the trail
+    int n = 0;
+    for (int p = parent; p >= 0 && n < RT_STACK; p = S.shapes[p].parent) chain[n++] = p;
+    return n;
+}
+RT_DEV V3 world_to_object(const SceneDev& S, const RtShape* __restrict__ sh, const int* chain, int n, V3 p) {
+    for (int k = n - 1; k >= 0; --k) p = mul_point(S.shapes[chain[k]].inv, p);  // trail.iter().rev()
+    return mul_point(sh->inv, p);
+}
+RT_DEV V3 normal_to_world(const SceneDev& S, const RtShape* __restrict__ sh, const int* chain, int n, V3 nrm) {
+    V3 v = normalize(mul_vector_transposed(sh->inv, nrm));
+    for (int k = 0; k < n; ++k) v = normalize(mul_vector_transposed(S.shapes[chain[k]].inv, v));
+    return v;
+}
+RT_DEV V3 local_normal(const SceneDev& S, const RtShape* __restrict__ sh, unsigned kind, V3 p, const int* chain,
+                       int n, const Ray& world_ray) {
+    if (kind == RT_SPHERE) return p - v3(0.0, 0.0, 0.0);
+    if (kind == RT_PLANE) return v3(0.0, 1.0, 0.0);
+    if (kind == RT_CUBE) return cube_normal(p);
+    if (kind == RT_CYLINDER) {
+        const RtConic c = S.conics[sh->param];
+        return conic_normal(p, 0.0, c.minimum, c.maximum);
+    }
+    if (kind == RT_CONE) {
+        const RtConic c = S.conics[sh->param];
+        double y = hypot(p.x, p.z);
+        if (p.y > 0.0) y = -y;
+        return conic_normal(p, y, c.minimum, c.maximum);
+    }
+    const RtTriangle* __restrict__ tri = S.tris + sh->param;
+    const V3 n1 = v3(tri->n1[0], tri->n1[1], tri->n1[2]);
+    if (kind == RT_TRIANGLE) return n1;
+    // smooth triangle: the hit's (u, v) are those of the local intersection; rebuild the
+    // local ray exactly as the traversal did and recompute them (primitive.rs:221-224,365-373)
+    Ray r = world_ray;
+    for (int k = n - 1; k >= 0; --k) r = transform_ray(S.shapes[chain[k]].inv, r);
+    r = transform_ray(sh->inv, r);
+    double ts[1], u, v;
+    triangle_intersect(tri, r, ts, u, v);
+    const V3 n2 = v3(tri->n2[0], tri->n2[1], tri->n2[2]);
+    const V3 n3 = v3(tri->n3[0], tri->n3[1], tri->n3[2]);
+    return n2 * u + n3 * v + n1 * (1.0 - u - v);
+}
+
+// ---- Computations (intersection.rs:45-99,162-200) ---------------------------------------
+struct Comps {
+    int idx;
+    double t;
+    V3 over_point, under_point, eye_v, normal_v, reflect_v;
+    V3 object_over_point;  // world_to_object(over_point): what pattern_at_shape needs (pattern.rs:76-85)
+    bool inside;
+    double n1, n2;
+};
+
+// The containers walk of prepare_computations (intersection.rs:50-75) on the full sorted list.
+template <bool STATS>
+RT_DEV void containers_pass(const SceneDev& S, Scratch& W, const Ray& world_ray, double hit_t, double& n1, double& n2,
+                            Ctx<STATS>& cx) {
+    count(cx, ST_CONTAINER_PASSES);
+    W.rays[0] = world_ray;
+    // the walk stops at the first entry ~equal to the hit; entries that far beyond it
+    // cannot influence anything before it (dedupe windows are 1e-5 per nesting level)
+    const double bound = hit_t + 1e-3 + fabs(hit_t) * 1e-9;
+    const int n = list_eval(S, W, 0, (int)S.n_shapes, 0, 0, bound, cx);
+    uint32_t containers[RT_CONTAINERS_CAP];
+    int nc = 0;
+    n1 = 1.0;
+    n2 = 1.0;
+    for (int j = 0; j < n; ++j) {
+        const bool is_self = t_eq(W.lt[j], hit_t);
+        const uint32_t id = W.lid[j];
+        if (is_self && nc > 0) n1 = S.mats[S.shapes[containers[nc - 1]].material].refractive_index;
+        int pos = -1;
+        for (int k = 0; k < nc; ++k)
+            if (containers[k] == id && pos < 0) pos = k;
+        if (pos >= 0) {
+            for (int k = pos; k + 1 < nc; ++k) containers[k] = containers[k + 1];
+            --nc;
+        } else if (nc < RT_CONTAINERS_CAP) {
+            containers[nc++] = id;
+        } else {
+            cx.status |= RT_STATUS_LIST_OVERFLOW;
+        }
+        if (is_self) {
+            if (nc > 0) n2 = S.mats[S.shapes[containers[nc - 1]].material].refractive_index;
+            break;
+        }
+    }
+}
+
+template <bool STATS>
+RT_DEV void prepare_computations(const SceneDev& S, Scratch& W, const Ray& ray, const Best& hit, bool want_n1n2,
+                                 Comps& c, Ctx<STATS>& cx) {
+    count(cx, ST_HITS_SHADED);
+    const RtShape* __restrict__ sh = S.shapes + hit.idx;
+    const unsigned kind = RT_KIND(sh->kind_flags);
+    int chain[RT_STACK];
+    const int n = ancestor_chain(S, sh->parent, chain);
+    count(cx, ST_NORMAL_LEVELS, 2u * (unsigned)(n + 1));
+    const V3 point = ray.o + ray.d * hit.t;  // ray.rs:15-17
+    c.idx = hit.idx;
+    c.t = hit.t;
+    c.eye_v = -ray.d;
+    const V3 local_point = world_to_object(S, sh, chain, n, point);
+    V3 normal_v = normal_to_world(S, sh, chain, n, local_normal(S, sh, kind, local_point, chain, n, ray));
+    c.inside = dot(normal_v, c.eye_v) < 0.0;
+    if (c.inside) normal_v = -normal_v;
+    c.normal_v = normal_v;
+    c.over_point = point + normal_v * EPSILON;
+    c.under_point = point - normal_v * EPSILON;
+    c.reflect_v = reflect(ray.d, normal_v);
+    c.object_over_point = world_to_object(S, sh, chain, n, c.over_point);
+    c.n1 = 1.0;
+    c.n2 = 1.0;
+    if (want_n1n2) containers_pass(S, W, ray, hit.t, c.n1, c.n2, cx);
+}
+
+RT_DEV double schlick(const Comps& c) {  // intersection.rs:182-200
+    double cosv = dot(c.eye_v, c.normal_v);
+    if (c.n1 > c.n2) {
+        const double n = c.n1 / c.n2;
+        const double sin2_t = (n * n) * (1.0 - cosv * cosv);
+        if (sin2_t > 1.0) return 1.0;
+        cosv = sqrt(1.0 - sin2_t);
+    }
+    const double r = (c.n1 - c.n2) / (c.n1 + c.n2);
+    const double r0 = r * r;
+    const double x = 1.0 - cosv;
+    const double x2 = x * x;  // powi(5) == x^2 -> x^4 -> x^4 * x (Q11)
+    const double x4 = x2 * x2;
+    return r0 + (1.0 - r0) * (x4 * x);
+}
+
+// World::is_shadowed (world.rs:85-96)
+template <bool STATS>
+RT_DEV bool is_shadowed(const SceneDev& S, Scratch& W, V3 point, V3 light_position, Ctx<STATS>& cx) {
+    const V3 v = light_position - point;
+    const double distance = magnitude(v);
+    const Ray r{point, normalize(v)};
+    count(cx, ST_RAY_SHADOW);
+    if (S.flags & RT_SCENE_HAS_SHADOWLESS) {
+        // exact-tie replacement between a shadowless and a shadow-casting primitive can
+        // decide the answer: evaluate the set itself (see file header)
+        W.rays[0] = r;
+        const double bound = distance + 1e-3 + distance * 1e-9;  // margin: see containers_pass
+        const int n = list_eval(S, W, 0, (int)S.n_shapes, 0, 0, bound, cx);
+        for (int j = 0; j < n; ++j) {
+            const double t = W.lt[j];
+            if (t >= 0.0 && (S.shapes[W.lid[j]].kind_flags & RT_FLAG_HAS_SHADOW)) return t < distance;
+        }
+        return false;
+    }
+    Best unused{0.0, -1};
+    return traverse<true>(S, W, r, distance, unused, cx);
+}
+
+// Primitive::lighting (primitive.rs:111-151); `color` is the material or pattern colour.
+template <bool STATS>
+RT_DEV V3 lighting(const RtMaterial& m, V3 color, const RtLight& light, V3 position, V3 eye_v, V3 normal_v,
+                   bool in_shadow, Ctx<STATS>& cx) {
+    count(cx, ST_LIGHTINGS);
+    const V3 intensity = v3(light.intensity[0], light.intensity[1], light.intensity[2]);
+    const V3 effective_color = hadamard(color, intensity);
+    const V3 light_v = normalize(v3(light.position[0], light.position[1], light.position[2]) - position);
+    const V3 ambient = effective_color * m.ambient;
+    V3 diffuse = v3(0.0, 0.0, 0.0), specular = v3(0.0, 0.0, 0.0);
+    const double light_dot_normal = dot(light_v, normal_v);
+    if (!(light_dot_normal < 0.0 || in_shadow)) {
+        diffuse = (effective_color * m.diffuse) * light_dot_normal;
+        const V3 reflect_v = reflect(-light_v, normal_v);
+        const double reflect_dot_eye = dot(reflect_v, eye_v);
+        if (!(reflect_dot_eye <= 0.0)) {
+            count(cx, ST_POW);
+            const double factor = pow(reflect_dot_eye, m.shininess);
+            specular = (intensity * m.specular) * factor;
+        }
+    }
+    return (ambient + diffuse) + specular;
+}
+
+// ---- World::color_at with the recursion unrolled (world.rs:32-127) ----------------------
+// A frame is one shade_hit waiting for its reflected and/or refracted child colour.
+struct Frame {
+    V3 surface;
+    V3 reflected;
+    Ray refract_ray;
+    double reflective, transparency, reflectance;
+    int state;  // see below
+    int use_schlick;
+};
+enum { FR_REFLECT_THEN_REFRACT = 0, FR_REFLECT_ONLY = 1, FR_REFRACT = 2 };
+
+RT_DEV V3 combine(V3 surface, V3 reflected, V3 refracted, bool use_schlick, double reflectance) {  // world.rs:76-82
+    if (use_schlick) return (surface + reflected * reflectance) + refracted * (1.0 - reflectance);
+    return (surface + reflected) + refracted;
+}
+
+template <bool STATS>
+RT_DEV bool find_hit(const SceneDev& S, Scratch& W, const Ray& ray, Best& best, Ctx<STATS>& cx) {
+    best.t = __builtin_inf();
+    best.idx = -1;
+    traverse<false>(S, W, ray, 0.0, best, cx);
+    return best.idx >= 0;
+}
+
+template <bool STATS>
+RT_DEV V3 color_at(const SceneDev& S, Scratch& W, Frame* frames, Ray ray, int remaining, Ctx<STATS>& cx) {
+    int sp = 0;
+    V3 value = v3(0.0, 0.0, 0.0);
+    for (;;) {
+        // ---- one World::color_at node, up to the point where it needs its children
+        Best hit;
+        bool descend = false;
+        if (!find_hit(S, W, ray, hit, cx)) {
+            value = v3(0.0, 0.0, 0.0);
+        } else {
+            const RtShape* __restrict__ sh = S.shapes + hit.idx;
+            const RtMaterial m = S.mats[sh->material];
+            // n1/n2 are consumed only by refracted_color past its `transparency == 0 ||
+            // remaining == 0` exit and by schlick(), whose value multiplies BLACK when
+            // remaining == 0 -- skip the pass where nothing can read it.
+            const bool want_n = m.transparency != 0.0 && remaining != 0;
+            Comps c;
+            prepare_computations(S, W, ray, hit, want_n, c, cx);
+            V3 color = v3(m.color[0], m.color[1], m.color[2]);
+            if (m.pattern >= 0) {
+                unsigned nodes = 0;
+                color = pattern_eval(S.pats, m.pattern, c.object_over_point, nodes);
+                count(cx, ST_PATTERN_NODES, nodes);
+            }
+            V3 surface = v3(0.0, 0.0, 0.0);
+            for (uint32_t li = 0; li < S.n_lights; ++li) {
+                const RtLight light = S.lights[li];
+                const bool shadowed =
+                    is_shadowed(S, W, c.over_point, v3(light.position[0], light.position[1], light.position[2]), cx);
+                surface = surface + lighting(m, color, light, c.over_point, c.eye_v, c.normal_v, shadowed, cx);
+            }
+            const bool do_reflect = !(m.reflective == 0.0 || remaining == 0);  // world.rs:99
+            bool do_refract = false;
+            Ray refract_ray = ray;
+            if (want_n) {  // world.rs:109-127
+                const double n_ratio = c.n1 / c.n2;
+                const double cos_i = dot(c.eye_v, c.normal_v);
+                const double sin2_t = (n_ratio * n_ratio) * (1.0 - cos_i * cos_i);
+                if (!(sin2_t > 1.0)) {
+                    const double cos_t = sqrt(1.0 - sin2_t);
+                    do_refract = true;
+                    refract_ray.o = c.under_point;
+                    refract_ray.d = c.normal_v * (n_ratio * cos_i - cos_t) - c.eye_v * n_ratio;
+                }
+            }
+            const bool use_schlick = m.reflective > 0.0 && m.transparency > 0.0;
+            double reflectance = 0.0;
+            if (use_schlick && remaining != 0) {
+                count(cx, ST_SCHLICK);
+                reflectance = schlick(c);
+            }
+            if (do_reflect || do_refract) {
+                Frame& f = frames[sp];
+                f.surface = surface;
+                f.reflected = v3(0.0, 0.0, 0.0);
+                f.refract_ray = refract_ray;
+                f.reflective = m.reflective;
+                f.transparency = m.transparency;
+                f.reflectance = reflectance;
+                f.use_schlick = use_schlick ? 1 : 0;
+                f.state = do_reflect ? (do_refract ? FR_REFLECT_THEN_REFRACT : FR_REFLECT_ONLY) : FR_REFRACT;
+                ++sp;
+                --remaining;
+                if (do_reflect) {
+                    count(cx, ST_RAY_REFLECT);
+                    ray = Ray{c.over_point, c.reflect_v};
+                } else {
+                    count(cx, ST_RAY_REFRACT);
+                    ray = refract_ray;
+                }
+                descend = true;
+            } else {
+                value = combine(surface, v3(0.0, 0.0, 0.0), v3(0.0, 0.0, 0.0), use_schlick, reflectance);
+            }
+        }
+        if (descend) continue;
+        // ---- hand `value` to the waiting frames
+        for (;;) {
+            if (sp == 0) return value;
+            Frame& f = frames[sp - 1];
+            if (f.state == FR_REFLECT_THEN_REFRACT) {
+                f.reflected = value * f.reflective;
+                f.state = FR_REFRACT;
+                ray = f.refract_ray;
+                count(cx, ST_RAY_REFRACT);
+                descend = true;
+                break;
+            }
+            V3 reflected, refracted;
+            if (f.state == FR_REFLECT_ONLY) {
+                reflected = value * f.reflective;
+                refracted = v3(0.0, 0.0, 0.0);
+            } else {
+                reflected = f.reflected;
+                refracted = value * f.transparency;
+            }
+            value = combine(f.surface, reflected, refracted, f.use_schlick != 0, f.reflectance);
+            --sp;
+            ++remaining;
+        }
+    }
+}
+
+// Camera::ray_for_pixel (camera.rs:68-80)
+RT_DEV Ray ray_for_pixel(const RtCameraDesc& cam, unsigned px, unsigned py) {
+    const double x_offset = ((double)px + 0.5) * cam.pixel_size;
+    const double y_offset = ((double)py + 0.5) * cam.pixel_size;
+    const double world_x = cam.half_width - x_offset;
+    const double world_y = cam.half_height - y_offset;
+    const V3 pixel = mul_point(cam.inv, v3(world_x, world_y, -1.0));
+    const V3 origin = mul_point(cam.inv, v3(0.0, 0.0, 0.0));
+    return Ray{origin, normalize(pixel - origin)};
+}
+
+}  // namespace rtd
