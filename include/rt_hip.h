@@ -170,6 +170,22 @@ typedef struct RtBvhNode {
     int32_t shape; /* leaf: shape index, inner: -1 */
 } RtBvhNode;
 
+/* Direction index (acceleration only).  The reference's Conic::intersect has a branch that
+ * reports a wall hit with NO y-range check when the ray is (nearly) parallel to the surface
+ * (|a| <= 1e-4, primitive.rs:486-490), so a truncated cylinder/cone can be "hit" anywhere along
+ * its infinite surface -- outside any box.  Whether the branch fires depends only on the ray
+ * DIRECTION: a = d^T Q d with Q fixed per conic.  For every truncated conic that sits under an
+ * acceleration structure the host stores Q (world space) and bins it into the cells of a cube
+ * map over directions; a ray looks up its cell, evaluates a for the few candidates listed
+ * there and, where |a| <= thr, tests that conic through its ancestor chain regardless of
+ * boxes.  q = {xx, yy, zz, xy, xz, yz}. */
+typedef struct RtDirCand {
+    double q[6];
+    double thr;        /* 1e-4 plus rounding slack */
+    uint32_t shape;    /* the conic                                              */
+    uint32_t visit;    /* what to evaluate: the conic, or its outermost CSG ancestor */
+} RtDirCand;
+
 typedef struct RtSceneDesc {
     uint32_t n_shapes;
     const RtShape* shapes;
@@ -192,7 +208,12 @@ typedef struct RtSceneDesc {
     uint32_t n_bvh_nodes;
     const RtBvhNode* bvh_nodes;
     int32_t world_bvh_root; /* acceleration over top-level shapes, -1 = none */
-    uint32_t reserved;
+    uint32_t dir_res;       /* direction index: cells per cube-face edge, 0 = no index */
+    uint32_t n_dir_cands;
+    const RtDirCand* dir_cands;
+    uint32_t n_dir_entries;
+    const uint32_t* dir_cell_start; /* 6*dir_res^2 + 1 offsets into dir_entries */
+    const uint32_t* dir_entries;    /* candidate indices, grouped by cell         */
 } RtSceneDesc;
 
 /* Camera (camera.rs:13-21): everything Camera::new / with_transform cached. */

@@ -88,6 +88,10 @@ class RtBvhNode(C.Structure):
     _fields_ = [("bmin", C.c_double * 3), ("bmax", C.c_double * 3), ("miss", C.c_int32), ("shape", C.c_int32)]
 
 
+class RtDirCand(C.Structure):
+    _fields_ = [("q", C.c_double * 6), ("thr", C.c_double), ("shape", C.c_uint32), ("visit", C.c_uint32)]
+
+
 class RtSceneDesc(C.Structure):
     _fields_ = [("n_shapes", C.c_uint32), ("shapes", C.POINTER(RtShape)),
                 ("n_conics", C.c_uint32), ("conics", C.POINTER(RtConic)),
@@ -99,7 +103,10 @@ class RtSceneDesc(C.Structure):
                 ("n_patterns", C.c_uint32), ("patterns", C.POINTER(RtPattern)),
                 ("n_lights", C.c_uint32), ("lights", C.POINTER(RtLight)),
                 ("n_bvh_nodes", C.c_uint32), ("bvh_nodes", C.POINTER(RtBvhNode)),
-                ("world_bvh_root", C.c_int32), ("reserved", C.c_uint32)]
+                ("world_bvh_root", C.c_int32), ("dir_res", C.c_uint32),
+                ("n_dir_cands", C.c_uint32), ("dir_cands", C.POINTER(RtDirCand)),
+                ("n_dir_entries", C.c_uint32), ("dir_cell_start", C.POINTER(C.c_uint32)),
+                ("dir_entries", C.POINTER(C.c_uint32))]
 
 
 class RtCameraDesc(C.Structure):

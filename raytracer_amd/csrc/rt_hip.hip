@@ -246,6 +246,9 @@ int validate(const RtSceneDesc& d, uint32_t* flags_out) {
                 const RtGroup& g = d.groups[s.param];
                 if (g.bvh_root < -1 || g.bvh_root >= (int32_t)d.n_bvh_nodes) return RT_ERR_INVALID_SCENE;
                 if ((g.n_children == 0) != (s.skip == i + 1)) return RT_ERR_INVALID_SCENE;
+                if (g.bvh_root >= 0)  // CSG operands are always scanned linearly (direction index contract)
+                    for (uint32_t a : open)
+                        if (RT_KIND(d.shapes[a].kind_flags) == RT_CSG) return RT_ERR_INVALID_SCENE;
             } else {
                 if (s.param >= d.n_csgs) return RT_ERR_INVALID_SCENE;
                 const RtCsg& c = d.csgs[s.param];
@@ -278,6 +281,27 @@ int validate(const RtSceneDesc& d, uint32_t* flags_out) {
         if (nd.shape < 0 && k + 1 >= d.n_bvh_nodes) return RT_ERR_INVALID_SCENE;  // inner node needs a successor
     }
     if (d.world_bvh_root < -1 || d.world_bvh_root >= (int32_t)d.n_bvh_nodes) return RT_ERR_INVALID_SCENE;
+    // direction index: offsets monotone and inside the entry list, entries name candidates,
+    // candidates name a conic and the shape to evaluate for it (itself or an enclosing CSG)
+    if (d.dir_res != 0) {
+        if (d.dir_res > 2048 || !d.dir_cell_start || !need(d.n_dir_cands, d.dir_cands) ||
+            !need(d.n_dir_entries, d.dir_entries))
+            return RT_ERR_INVALID_ARG;
+        const size_t n_cells = (size_t)6 * d.dir_res * d.dir_res;
+        if (d.dir_cell_start[0] != 0 || d.dir_cell_start[n_cells] != d.n_dir_entries) return RT_ERR_INVALID_SCENE;
+        for (size_t c = 0; c < n_cells; ++c)
+            if (d.dir_cell_start[c] > d.dir_cell_start[c + 1]) return RT_ERR_INVALID_SCENE;
+        for (uint32_t k = 0; k < d.n_dir_entries; ++k)
+            if (d.dir_entries[k] >= d.n_dir_cands) return RT_ERR_INVALID_SCENE;
+        for (uint32_t k = 0; k < d.n_dir_cands; ++k) {
+            const RtDirCand& c = d.dir_cands[k];
+            if (c.shape >= d.n_shapes || c.visit >= d.n_shapes) return RT_ERR_INVALID_SCENE;
+            const unsigned ck = RT_KIND(d.shapes[c.shape].kind_flags), vk = RT_KIND(d.shapes[c.visit].kind_flags);
+            if (ck != RT_CYLINDER && ck != RT_CONE) return RT_ERR_INVALID_SCENE;
+            if (!(c.visit == c.shape || (vk == RT_CSG && c.visit < c.shape && c.shape < d.shapes[c.visit].skip)))
+                return RT_ERR_INVALID_SCENE;
+        }
+    }
     *flags_out = flags;
     return RT_OK;
 }
@@ -407,6 +431,13 @@ int rt_hip_scene_create(const RtSceneDesc* desc, RtScene** out) {
     up(desc->patterns, desc->n_patterns, &pats);
     up(desc->lights, desc->n_lights, &lights);
     up(desc->bvh_nodes, desc->n_bvh_nodes, &bvh);
+    RtDirCand* dir_cands = nullptr;
+    uint32_t *dir_cell_start = nullptr, *dir_entries = nullptr;
+    if (desc->dir_res != 0) {
+        up(desc->dir_cands, desc->n_dir_cands, &dir_cands);
+        up(desc->dir_cell_start, (size_t)6 * desc->dir_res * desc->dir_res + 1, &dir_cell_start);
+        up(desc->dir_entries, desc->n_dir_entries, &dir_entries);
+    }
     if (rc == RT_OK) {
         const hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->d_status), sizeof(unsigned));
         if (e != hipSuccess) rc = hip_fail(e, "hipMalloc(status)");
@@ -422,6 +453,9 @@ int rt_hip_scene_create(const RtSceneDesc* desc, RtScene** out) {
     }
     s->dev.shapes = shapes, s->dev.conics = conics, s->dev.tris = tris, s->dev.groups = groups, s->dev.csgs = csgs;
     s->dev.lhit = lhit, s->dev.mats = mats, s->dev.pats = pats, s->dev.lights = lights, s->dev.bvh = bvh;
+    s->dev.dir_cands = dir_cands, s->dev.dir_cell_start = dir_cell_start, s->dev.dir_entries = dir_entries;
+    s->dev.dir_res = desc->n_dir_cands ? desc->dir_res : 0u;
+    s->dev.n_dir_cands = desc->n_dir_cands;
     s->dev.n_shapes = desc->n_shapes;
     s->dev.n_lights = desc->n_lights;
     s->dev.world_bvh_root = desc->world_bvh_root;

@@ -28,7 +28,7 @@
 namespace rtd {
 
 #define RT_STACK (RT_MAX_NEST + 2)
-#define RT_CONTAINERS_CAP 24
+#define RT_CONTAINERS_CAP RT_LIST_CAP
 #define RT_SCENE_HAS_SHADOWLESS 1u
 
 struct SceneDev {
@@ -42,6 +42,10 @@ struct SceneDev {
     const RtPattern* __restrict__ pats;
     const RtLight* __restrict__ lights;
     const RtBvhNode* __restrict__ bvh;
+    const RtDirCand* __restrict__ dir_cands;
+    const uint32_t* __restrict__ dir_cell_start;
+    const uint32_t* __restrict__ dir_entries;
+    uint32_t dir_res, n_dir_cands;
     uint32_t n_shapes, n_lights;
     int32_t world_bvh_root;
     uint32_t flags;
@@ -150,12 +154,14 @@ RT_DEV void prim_intersect(const SceneDev& S, const RtShape* __restrict__ sh, un
 }
 
 // ---- sorted hit list (stands for BTreeSet<Intersection>) -----------------------
-// BTreeSet::append of one element (Q1): on a bit-equal t the new entry replaces the old.
+// BTreeSet::append of one element (Q1): on a bit-equal t the entry of the shape that comes
+// later in depth-first order survives (a linear scan inserts in that order anyway; a walk
+// through an acceleration structure does not, hence the explicit comparison).
 RT_DEV int list_insert(Scratch& W, int base, int top, double t, uint32_t id, unsigned& status) {
     int pos = top;
     while (pos > base && W.lt[pos - 1] > t) --pos;
     if (pos > base && W.lt[pos - 1] == t) {
-        W.lid[pos - 1] = id;
+        if (id > W.lid[pos - 1]) W.lid[pos - 1] = id;
         return top;
     }
     if (top >= RT_LIST_CAP) {
@@ -216,67 +222,128 @@ RT_DEV int csg_filter(const SceneDev& S, Scratch& W, int b, int top, int g, unsi
     return m;
 }
 
-// Sorted intersections of the sibling shapes [begin, end) -- all at nesting level
-// `level0`, whose ray is W.rays[level0] -- appended at W.lt/lid[base0 ..).  Entries with
+// Acceleration-only slab test of the whole LINE against a padded box, cut at t <= bound.
+RT_DEV bool accel_line_box(const RtBvhNode* __restrict__ nd, const V3& o, const V3& inv_d, double bound) {
+    const double ax = (nd->bmin[0] - o.x) * inv_d.x, bx = (nd->bmax[0] - o.x) * inv_d.x;
+    const double ay = (nd->bmin[1] - o.y) * inv_d.y, by = (nd->bmax[1] - o.y) * inv_d.y;
+    const double az = (nd->bmin[2] - o.z) * inv_d.z, bz = (nd->bmax[2] - o.z) * inv_d.z;
+    const double t0 = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmin(az, bz));
+    const double t1 = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmax(az, bz));
+    return !(t0 > t1) && !(t0 > bound);
+}
+
+// Sorted intersections of the sibling shapes [begin, end) -- all at nesting level `level0`,
+// whose ray is W.rays[level0] -- merged into the list W.lt/lid[base0, top0).  Entries with
 // t > bound are not recorded (callers pass a bound that leaves a margin wider than every
 // dedupe window between the entries they read and the cut).  Returns the new top.
+// Group members go straight into the list of the nearest enclosing CSG node (or the root
+// list): a group's merge is a set union with the tie rule of list_insert.  A CSG node gets a
+// sub-list of its own, filtered when its subtree is done and then merged downwards.
+// With USE_BVH the world level and groups that carry an acceleration structure are walked
+// through it (groups inside CSG nodes never carry one: see the flattener).
 // Shape::intersect / Compound::local_intersect / World::intersections
 // (shape.rs:28-32, compound.rs:87-117, world.rs:45-53).
-template <bool STATS>
-RT_DEV int list_eval(const SceneDev& S, Scratch& W, int begin, int end, int level0, int base0, double bound,
-                     Ctx<STATS>& cx) {
+template <bool USE_BVH, bool STATS>
+RT_DEV int list_eval_core(const SceneDev& S, Scratch& W, int begin, int end, int level0, int base0, int top0,
+                          double bound, Ctx<STATS>& cx) {
     int level = level0;
-    int top = base0;
-    int base = base0;  // start of the list of the compound open at `level`
-    int i = begin;
+    int top = top0;
+    int base = base0;  // start of the list entries currently go to
+    Ray ray = W.rays[level0];
+    bool bvh = USE_BVH && level0 == 0 && S.world_bvh_root >= 0;
+    int cur = bvh ? S.world_bvh_root : begin;
+    int lend = end;
+    V3 inv_d = v3(1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z);
     for (;;) {
-        while (level > level0 && i >= (int)S.shapes[W.fnode[level]].skip) {  // subtree finished
+        int s = -1;
+        if (USE_BVH && bvh) {
+            if (cur >= 0) {
+                const RtBvhNode* __restrict__ nd = S.bvh + cur;
+                count(cx, ST_BVH_BOX);
+                if (!accel_line_box(nd, ray.o, inv_d, bound)) {
+                    cur = nd->miss;
+                    continue;
+                }
+                const int leaf = nd->shape;
+                if (leaf < 0) {
+                    ++cur;
+                    continue;
+                }
+                s = leaf;
+                cur = nd->miss;
+            }
+        } else if (cur < lend) {
+            s = cur;
+            cur = (int)S.shapes[s].skip;
+        }
+        if (s < 0) {  // level exhausted
+            if (level == level0) break;
             const int g = W.fnode[level];
             const RtShape* __restrict__ gs = S.shapes + g;
             if (RT_KIND(gs->kind_flags) == RT_CSG) {
                 const RtCsg c = S.csgs[gs->param];
                 top = csg_filter(S, W, base, top, g, c.op, c.lhit_offset);
+                const int parent_base = W.fbase[level];
+                top = list_merge(W, parent_base, base, top, cx.status);
+                base = parent_base;
             }
-            const int parent_base = level - 1 > level0 ? W.fbase[level - 1] : base0;
-            top = list_merge(W, parent_base, base, top, cx.status);
-            base = parent_base;
             --level;
+            ray = W.rays[level];
+            cur = W.cur[level];
+            lend = W.end[level];
+            bvh = USE_BVH && lend == -2;
+            if (USE_BVH && bvh) inv_d = v3(1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z);
+            continue;
         }
-        if (i >= end) break;
-        const RtShape* __restrict__ sh = S.shapes + i;
+        const RtShape* __restrict__ sh = S.shapes + s;
         const unsigned kf = sh->kind_flags;
         const unsigned kind = RT_KIND(kf);
         if (kind <= RT_SMOOTH_TRIANGLE) {
             PrimHits h;
-            prim_intersect(S, sh, kf, W.rays[level], h, cx);
+            prim_intersect(S, sh, kf, ray, h, cx);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (((h.keep >> k) & 1u) && h.t[k] <= bound) {
-                    top = list_insert(W, base, top, h.t[k], (uint32_t)i, cx.status);
+                    top = list_insert(W, base, top, h.t[k], (uint32_t)s, cx.status);
                     count(cx, ST_LIST_ENTRIES);
                 }
             }
-            ++i;
             continue;
         }
-        const Ray lr = transform_ray(sh->inv, W.rays[level]);
+        const Ray lr = transform_ray(sh->inv, ray);
         count(cx, ST_RAY_XFORM);
+        int root = -1;
         if (kind == RT_GROUP) {
             const RtGroup* __restrict__ g = S.groups + sh->param;
             count(cx, ST_GATES);
-            if (g->n_children == 0u || !box_intersects(g->bmin, g->bmax, lr)) {  // compound.rs:93-95
-                i = (int)sh->skip;
-                continue;
-            }
+            if (g->n_children == 0u || !box_intersects(g->bmin, g->bmax, lr)) continue;  // compound.rs:93-95
+            root = USE_BVH ? g->bvh_root : -1;
         }
+        W.rays[level] = ray;
+        W.cur[level] = cur;
+        W.end[level] = bvh ? -2 : lend;
         ++level;
-        W.rays[level] = lr;
-        W.fnode[level] = i;
-        W.fbase[level] = top;
-        base = top;
-        ++i;
+        W.fnode[level] = s;
+        W.fbase[level] = base;
+        if (kind == RT_CSG) base = top;
+        ray = lr;
+        bvh = USE_BVH && root >= 0;
+        if (USE_BVH && bvh) {
+            cur = root;
+            inv_d = v3(1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z);
+        } else {
+            cur = s + 1;
+            lend = (int)sh->skip;
+        }
     }
     return top;
+}
+
+// A compound subtree evaluated on its own (CSG nodes met by the streaming traversal).
+template <bool STATS>
+RT_DEV int list_eval(const SceneDev& S, Scratch& W, int begin, int end, int level0, int base0, double bound,
+                     Ctx<STATS>& cx) {
+    return list_eval_core<false>(S, W, begin, end, level0, base0, base0, bound, cx);
 }
 
 // ---- streaming world traversal ---------------------------------------------------
@@ -303,6 +370,136 @@ RT_DEV bool accel_box(const RtBvhNode* __restrict__ nd, const V3& o, const V3& i
     return !(t0 > t1) && !(t1 < 0.0) && !(t0 > t_far);
 }
 
+RT_DEV int ancestor_chain(const SceneDev& S, int parent, int* chain) {  // innermost first == the trail
+    int n = 0;
+    for (int p = parent; p >= 0 && n < RT_STACK; p = S.shapes[p].parent) chain[n++] = p;
+    return n;
+}
+
+// One non-group shape `s` met with the ray of its enclosing level (`level` = its nesting depth):
+// a primitive is intersected, a CSG node is materialised through list_eval; the surviving hits go
+// to the closest-hit reduction or the shadow test.  Returns true when a shadow hit was found.
+template <bool SHADOW, bool STATS>
+RT_DEV bool process_leaf(const SceneDev& S, Scratch& W, int s, const RtShape* __restrict__ sh, unsigned kf,
+                         const Ray& ray, int level, double limit, Best& best, Ctx<STATS>& cx) {
+    if (RT_KIND(kf) <= RT_SMOOTH_TRIANGLE) {
+        if (SHADOW && !(kf & RT_FLAG_HAS_SHADOW)) return false;
+        PrimHits h;
+        prim_intersect(S, sh, kf, ray, h, cx);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if ((h.keep >> k) & 1u) {
+                if (SHADOW) {
+                    if (h.t[k] >= 0.0 && h.t[k] < limit) return true;
+                } else {
+                    offer(best, h.t[k], s);
+                }
+            }
+        }
+        return false;
+    }
+    W.rays[level] = ray;
+    const int n = list_eval(S, W, s, (int)sh->skip, level, 0, __builtin_inf(), cx);
+    for (int j = 0; j < n; ++j) {
+        const double t = W.lt[j];
+        const int id = (int)W.lid[j];
+        if (SHADOW) {
+            if ((S.shapes[id].kind_flags & RT_FLAG_HAS_SHADOW) && t >= 0.0 && t < limit) return true;
+        } else {
+            offer(best, t, id);
+        }
+    }
+    return false;
+}
+
+// Direction index (RtDirCand): conics whose "ray parallel to the surface" branch
+// (primitive.rs:486-490, no y-range check) fires for this ray direction must be evaluated
+// whatever the acceleration boxes say.  Calls f(node, shape record, ray at the node's level,
+// level) for each such conic (or its outermost CSG ancestor) that the reference's own group
+// gates let the ray reach; f returns true to stop.  A shape evaluated here and met again by the
+// box walk contributes the same hits twice, which changes nothing.
+template <bool STATS, class F>
+RT_DEV bool for_each_direction_candidate(const SceneDev& S, const Ray& ray, Ctx<STATS>& cx, F&& f) {
+    const V3 d = ray.d;
+    const double len2 = dot(d, d);
+    // the cells are built for unit directions; a shorter direction widens the region
+    const bool scan_all = !(len2 >= 0.999999);
+    uint32_t b = 0, e = S.n_dir_cands;
+    if (!scan_all) {
+        const double ax = fabs(d.x), ay = fabs(d.y), az = fabs(d.z);
+        int face;
+        double m, u, v;
+        if (ax >= ay && ax >= az) {
+            face = d.x >= 0.0 ? 0 : 1, m = ax, u = d.y, v = d.z;
+        } else if (ay >= az) {
+            face = d.y >= 0.0 ? 2 : 3, m = ay, u = d.x, v = d.z;
+        } else {
+            face = d.z >= 0.0 ? 4 : 5, m = az, u = d.x, v = d.y;
+        }
+        const double R = (double)S.dir_res;
+        int i = (int)((u / m + 1.0) * 0.5 * R);
+        int j = (int)((v / m + 1.0) * 0.5 * R);
+        const int hi = (int)S.dir_res - 1;
+        i = i < 0 ? 0 : (i > hi ? hi : i);
+        j = j < 0 ? 0 : (j > hi ? hi : j);
+        const uint32_t cell = ((uint32_t)face * S.dir_res + (uint32_t)j) * S.dir_res + (uint32_t)i;
+        b = S.dir_cell_start[cell];
+        e = S.dir_cell_start[cell + 1];
+    }
+    for (uint32_t k = b; k < e; ++k) {
+        const RtDirCand* __restrict__ c = S.dir_cands + (scan_all ? k : S.dir_entries[k]);
+        const double a = c->q[0] * d.x * d.x + c->q[1] * d.y * d.y + c->q[2] * d.z * d.z +
+                         2.0 * (c->q[3] * d.x * d.y + c->q[4] * d.x * d.z + c->q[5] * d.y * d.z);
+        if (!(fabs(a) <= c->thr)) continue;
+        // walk down to the shape exactly as the traversal would: transforms and group gates
+        const int node = (int)c->visit;
+        const RtShape* __restrict__ sh = S.shapes + node;
+        int chain[RT_STACK];
+        const int n = ancestor_chain(S, sh->parent, chain);
+        Ray r = ray;
+        bool reachable = true;
+        for (int q = n - 1; q >= 0 && reachable; --q) {
+            const RtShape* __restrict__ g = S.shapes + chain[q];
+            r = transform_ray(g->inv, r);
+            count(cx, ST_RAY_XFORM);
+            if (RT_KIND(g->kind_flags) == RT_GROUP) {
+                const RtGroup* __restrict__ gg = S.groups + g->param;
+                count(cx, ST_GATES);
+                reachable = gg->n_children != 0u && box_intersects(gg->bmin, gg->bmax, r);
+            }
+        }
+        if (!reachable) continue;
+        if (f(node, sh, r, n)) return true;
+    }
+    return false;
+}
+
+// World::intersections (world.rs:45-53) as a sorted list at W.lt/lid[0, n), cut at t <= bound.
+template <bool STATS>
+RT_DEV int world_list(const SceneDev& S, Scratch& W, const Ray& ray, double bound, Ctx<STATS>& cx) {
+    int top = 0;
+    if (S.dir_res != 0u) {
+        for_each_direction_candidate(S, ray, cx, [&](int node, const RtShape* __restrict__ sh, const Ray& r, int n) {
+            const unsigned kf = sh->kind_flags;
+            if (RT_KIND(kf) <= RT_SMOOTH_TRIANGLE) {
+                PrimHits h;
+                prim_intersect(S, sh, kf, r, h, cx);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (((h.keep >> k) & 1u) && h.t[k] <= bound)
+                        top = list_insert(W, 0, top, h.t[k], (uint32_t)node, cx.status);
+            } else {
+                W.rays[n] = r;
+                const int t2 = list_eval_core<false>(S, W, node, (int)sh->skip, n, top, top, bound, cx);
+                top = list_merge(W, 0, top, t2, cx.status);
+            }
+            return false;
+        });
+    }
+    W.rays[0] = ray;
+    return list_eval_core<true>(S, W, 0, (int)S.n_shapes, 0, 0, top, bound, cx);
+}
+
 // SHADOW == false: closest hit into `best`.  SHADOW == true: returns true as soon as a
 // shadow-casting primitive is met at 0 <= t < limit (world.rs:85-96).
 template <bool SHADOW, bool STATS>
@@ -313,6 +510,11 @@ RT_DEV bool traverse(const SceneDev& S, Scratch& W, const Ray& world_ray, double
     int cur = bvh ? S.world_bvh_root : 0;
     int end = (int)S.n_shapes;
     V3 inv_d = v3(1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z);
+    if (S.dir_res != 0u &&
+        for_each_direction_candidate(S, world_ray, cx, [&](int node, const RtShape* __restrict__ sh, const Ray& r, int n) {
+            return process_leaf<SHADOW>(S, W, node, sh, sh->kind_flags, r, n, limit, best, cx);
+        }))
+        return true;
     for (;;) {
         int s = -1;
         if (bvh) {
@@ -349,23 +551,11 @@ RT_DEV bool traverse(const SceneDev& S, Scratch& W, const Ray& world_ray, double
         const RtShape* __restrict__ sh = S.shapes + s;
         const unsigned kf = sh->kind_flags;
         const unsigned kind = RT_KIND(kf);
-        if (kind <= RT_SMOOTH_TRIANGLE) {
-            if (SHADOW && !(kf & RT_FLAG_HAS_SHADOW)) continue;
-            PrimHits h;
-            prim_intersect(S, sh, kf, ray, h, cx);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if ((h.keep >> k) & 1u) {
-                    if (SHADOW) {
-                        if (h.t[k] >= 0.0 && h.t[k] < limit) return true;
-                    } else {
-                        offer(best, h.t[k], s);
-                    }
-                }
-            }
+        if (kind != RT_GROUP) {
+            if (process_leaf<SHADOW>(S, W, s, sh, kf, ray, level, limit, best, cx)) return true;
             continue;
         }
-        if (kind == RT_GROUP) {
+        {
             const Ray lr = transform_ray(sh->inv, ray);
             const RtGroup* __restrict__ g = S.groups + sh->param;
             count(cx, ST_RAY_XFORM);
@@ -387,28 +577,11 @@ RT_DEV bool traverse(const SceneDev& S, Scratch& W, const Ray& world_ray, double
             }
             continue;
         }
-        // CSG: materialise the subtree's filtered list, then reduce its survivors
-        W.rays[level] = ray;
-        const int n = list_eval(S, W, s, (int)sh->skip, level, 0, __builtin_inf(), cx);
-        for (int j = 0; j < n; ++j) {
-            const double t = W.lt[j];
-            const int id = (int)W.lid[j];
-            if (SHADOW) {
-                if ((S.shapes[id].kind_flags & RT_FLAG_HAS_SHADOW) && t >= 0.0 && t < limit) return true;
-            } else {
-                offer(best, t, id);
-            }
-        }
     }
     return false;
 }
 
 // ---- object space / normals (primitive.rs:153-192) -----------------------------------
-RT_DEV int ancestor_chain(const SceneDev& S, int parent, int* chain) {  // innermost first == the trail
-    int n = 0;
-    for (int p = parent; p >= 0 && n < RT_STACK; p = S.shapes[p].parent) chain[n++] = p;
-    return n;
-}
 RT_DEV V3 world_to_object(const SceneDev& S, const RtShape* __restrict__ sh, const int* chain, int n, V3 p) {
     for (int k = n - 1; k >= 0; --k) p = mul_point(S.shapes[chain[k]].inv, p);  // trail.iter().rev()
     return mul_point(sh->inv, p);
@@ -463,11 +636,10 @@ template <bool STATS>
 RT_DEV void containers_pass(const SceneDev& S, Scratch& W, const Ray& world_ray, double hit_t, double& n1, double& n2,
                             Ctx<STATS>& cx) {
     count(cx, ST_CONTAINER_PASSES);
-    W.rays[0] = world_ray;
     // the walk stops at the first entry ~equal to the hit; entries that far beyond it
     // cannot influence anything before it (dedupe windows are 1e-5 per nesting level)
     const double bound = hit_t + 1e-3 + fabs(hit_t) * 1e-9;
-    const int n = list_eval(S, W, 0, (int)S.n_shapes, 0, 0, bound, cx);
+    const int n = world_list(S, W, world_ray, bound, cx);
     uint32_t containers[RT_CONTAINERS_CAP];
     int nc = 0;
     n1 = 1.0;
@@ -547,9 +719,8 @@ RT_DEV bool is_shadowed(const SceneDev& S, Scratch& W, V3 point, V3 light_positi
     if (S.flags & RT_SCENE_HAS_SHADOWLESS) {
         // exact-tie replacement between a shadowless and a shadow-casting primitive can
         // decide the answer: evaluate the set itself (see file header)
-        W.rays[0] = r;
         const double bound = distance + 1e-3 + distance * 1e-9;  // margin: see containers_pass
-        const int n = list_eval(S, W, 0, (int)S.n_shapes, 0, 0, bound, cx);
+        const int n = world_list(S, W, r, bound, cx);
         for (int j = 0; j < n; ++j) {
             const double t = W.lt[j];
             if (t >= 0.0 && (S.shapes[W.lid[j]].kind_flags & RT_FLAG_HAS_SHADOW)) return t < distance;

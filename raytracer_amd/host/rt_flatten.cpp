@@ -2,6 +2,7 @@
 #include "rt_flatten.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <map>
 #include <string>
@@ -14,9 +15,193 @@ void rows012(const Matrix4& m, double out[12]) {
         for (int j = 0; j < 4; ++j) out[i * 4 + j] = m.m[i][j];
 }
 
+// ---- acceleration structure (not part of the reference; never changes a result) -----------
+// A box that certainly contains every point at which the reference can report a hit of the
+// shape, in the space of the shape's parent.  Unlike Properties.bounds (the reference's
+// quirky fold, Q5) this one is a true bound: cones use their real radius, compounds the
+// union of their children.
+struct ABox {
+    double mn[3] = {INFINITY, INFINITY, INFINITY};  // empty
+    double mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    bool unbounded = false;
+    bool empty() const { return !unbounded && mn[0] > mx[0]; }
+    void add(const Point& p) {
+        const double c[3] = {p.x, p.y, p.z};
+        for (int a = 0; a < 3; ++a) {
+            if (!std::isfinite(c[a])) unbounded = true;
+            mn[a] = std::fmin(mn[a], c[a]);
+            mx[a] = std::fmax(mx[a], c[a]);
+        }
+    }
+    void merge(const ABox& o) {
+        if (o.unbounded) unbounded = true;
+        if (o.empty()) return;
+        for (int a = 0; a < 3; ++a) {
+            mn[a] = std::fmin(mn[a], o.mn[a]);
+            mx[a] = std::fmax(mx[a], o.mx[a]);
+        }
+    }
+    ABox transformed(const Matrix4& t) const {
+        ABox r;
+        if (unbounded) {
+            r.unbounded = true;
+            return r;
+        }
+        if (empty()) return r;
+        for (int k = 0; k < 8; ++k) r.add(t * Point(k & 1 ? mx[0] : mn[0], k & 2 ? mx[1] : mn[1], k & 4 ? mx[2] : mn[2]));
+        return r;
+    }
+    // Outward padding: rounding in the reference's intersection arithmetic can accept a ray
+    // that misses the exact surface by a relative ~1e-16 * (distance/size)^2; 1e-4 of the
+    // box diagonal covers origins up to ~1e6 object sizes away.
+    void pad() {
+        if (unbounded || empty()) return;
+        double diag = 0.0, big = 0.0;
+        for (int a = 0; a < 3; ++a) {
+            diag += (mx[a] - mn[a]) * (mx[a] - mn[a]);
+            big = std::fmax(big, std::fmax(std::fabs(mn[a]), std::fabs(mx[a])));
+        }
+        const double e = 1e-4 * std::sqrt(diag) + 1e-9 * big + 1e-12;
+        for (int a = 0; a < 3; ++a) mn[a] -= e, mx[a] += e;
+    }
+    double centroid(int a) const { return 0.5 * (mn[a] + mx[a]); }
+    double half_area() const {
+        const double x = mx[0] - mn[0], y = mx[1] - mn[1], z = mx[2] - mn[2];
+        return x * y + y * z + z * x;
+    }
+};
+
+ABox primitive_box(const Primitive& p) {
+    ABox b;
+    switch (p.kind()) {
+        case Primitive::Kind::Sphere:
+        case Primitive::Kind::Cube:
+            b.add(Point(-1.0, -1.0, -1.0)), b.add(Point(1.0, 1.0, 1.0));
+            break;
+        case Primitive::Kind::Plane: b.unbounded = true; break;
+        case Primitive::Kind::Cylinder:
+            b.add(Point(-1.0, p.conic().minimum, -1.0)), b.add(Point(1.0, p.conic().maximum, 1.0));
+            break;
+        case Primitive::Kind::Cone: {
+            const double r = std::fmax(std::fabs(p.conic().minimum), std::fabs(p.conic().maximum));
+            b.add(Point(-r, p.conic().minimum, -r)), b.add(Point(r, p.conic().maximum, r));
+            break;
+        }
+        default: b.add(p.p1), b.add(p.p2), b.add(p.p3); break;
+    }
+    return b.transformed(p.properties().transform);
+}
+
+struct BvhItem {
+    ABox box;
+    uint32_t shape;
+};
+
+// Skip-link layout in depth-first order: node i's subtree is [i, miss); a walk goes to i+1 on
+// a box hit and to `miss` on a miss or after a leaf.  Binned surface-area split.
+void build_bvh_range(std::vector<BvhItem>& items, size_t lo, size_t hi, int32_t after, std::vector<RtBvhNode>& nodes) {
+    const size_t n = hi - lo;
+    ABox all, cent;
+    for (size_t i = lo; i < hi; ++i) {
+        all.merge(items[i].box);
+        cent.add(Point(items[i].box.centroid(0), items[i].box.centroid(1), items[i].box.centroid(2)));
+    }
+    RtBvhNode node;
+    for (int a = 0; a < 3; ++a) node.bmin[a] = all.mn[a], node.bmax[a] = all.mx[a];
+    node.miss = after;
+    if (n == 1) {
+        node.shape = static_cast<int32_t>(items[lo].shape);
+        nodes.push_back(node);
+        return;
+    }
+    node.shape = -1;
+    // choose the split
+    int best_axis = 0;
+    size_t best_mid = lo + n / 2;
+    double best_cost = INFINITY;
+    constexpr int kBins = 16;
+    for (int a = 0; a < 3; ++a) {
+        const double c0 = cent.mn[a], c1 = cent.mx[a];
+        if (!(c1 > c0)) continue;
+        ABox bin_box[kBins];
+        size_t bin_n[kBins] = {};
+        const double scale = kBins / (c1 - c0);
+        for (size_t i = lo; i < hi; ++i) {
+            int b = static_cast<int>((items[i].box.centroid(a) - c0) * scale);
+            b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+            bin_box[b].merge(items[i].box);
+            ++bin_n[b];
+        }
+        double right_area[kBins];
+        size_t right_n[kBins];
+        ABox acc;
+        size_t cnt = 0;
+        for (int b = kBins - 1; b > 0; --b) {
+            acc.merge(bin_box[b]);
+            cnt += bin_n[b];
+            right_area[b] = cnt ? acc.half_area() : 0.0;
+            right_n[b] = cnt;
+        }
+        acc = ABox();
+        cnt = 0;
+        for (int b = 0; b + 1 < kBins; ++b) {
+            acc.merge(bin_box[b]);
+            cnt += bin_n[b];
+            if (cnt == 0 || right_n[b + 1] == 0) continue;
+            const double cost = acc.half_area() * static_cast<double>(cnt) +
+                                right_area[b + 1] * static_cast<double>(right_n[b + 1]);
+            if (cost < best_cost) {
+                best_cost = cost;
+                best_axis = a;
+                best_mid = lo + cnt;
+                // remember the plane through the bin boundary
+            }
+        }
+    }
+    // partition by centroid order along the chosen axis (nth_element keeps it deterministic enough:
+    // ties broken by shape index)
+    auto less = [best_axis](const BvhItem& x, const BvhItem& y) {
+        const double cx = x.box.centroid(best_axis), cy = y.box.centroid(best_axis);
+        return cx < cy || (cx == cy && x.shape < y.shape);
+    };
+    std::sort(items.begin() + static_cast<long>(lo), items.begin() + static_cast<long>(hi), less);
+    if (best_mid <= lo || best_mid >= hi) best_mid = lo + n / 2;
+    const size_t self = nodes.size();
+    nodes.push_back(node);
+    const size_t n_left = best_mid - lo;
+    const int32_t right_root = static_cast<int32_t>(self + 1 + (2 * n_left - 1));
+    build_bvh_range(items, lo, best_mid, right_root, nodes);
+    build_bvh_range(items, best_mid, hi, after, nodes);
+}
+
+// Returns the root index, or -1 when nothing was built.
+int32_t build_bvh(std::vector<BvhItem> items, std::vector<RtBvhNode>& nodes) {
+    std::vector<BvhItem> bounded, unbounded;
+    for (BvhItem& it : items) {
+        if (it.box.empty()) continue;  // nothing to hit in there
+        it.box.pad();
+        (it.box.unbounded ? unbounded : bounded).push_back(it);
+    }
+    if (bounded.empty() && unbounded.empty()) return -1;
+    const int32_t root = static_cast<int32_t>(nodes.size());
+    const size_t tree_nodes = bounded.empty() ? 0 : 2 * bounded.size() - 1;
+    const int32_t first_unbounded = static_cast<int32_t>(nodes.size() + tree_nodes);
+    if (!bounded.empty())
+        build_bvh_range(bounded, 0, bounded.size(), unbounded.empty() ? -1 : first_unbounded, nodes);
+    for (size_t k = 0; k < unbounded.size(); ++k) {  // always-visited leaves after the tree
+        RtBvhNode leaf;
+        for (int a = 0; a < 3; ++a) leaf.bmin[a] = -INFINITY, leaf.bmax[a] = INFINITY;
+        leaf.shape = static_cast<int32_t>(unbounded[k].shape);
+        leaf.miss = k + 1 < unbounded.size() ? first_unbounded + static_cast<int32_t>(k) + 1 : -1;
+        nodes.push_back(leaf);
+    }
+    return root;
+}
+
 struct Flattener {
     FlatScene out;
     FlattenOptions opt;
+    int csg_depth = 0;  // > 0 while emitting the operands of a CSG node: no acceleration structures there
     std::vector<const Primitive*> prim_of;            // by shape index, nullptr for compounds
     std::map<std::string, uint32_t> material_cache;   // identical materials share one record
 
@@ -68,7 +253,8 @@ struct Flattener {
         return idx;
     }
 
-    uint32_t emit(const Shape& s, int32_t parent, uint32_t depth) {
+    // Appends the subtree of `s`; returns its acceleration box in the parent's space.
+    ABox emit(const Shape& s, int32_t parent, uint32_t depth) {
         const uint32_t idx = static_cast<uint32_t>(out.shapes.size());
         out.shapes.emplace_back();
         prim_of.push_back(nullptr);
@@ -110,10 +296,11 @@ struct Flattener {
             }
             rec.skip = idx + 1;
             out.shapes[idx] = rec;
-            return idx;
+            return primitive_box(p);
         }
 
         const Compound& c = s.compound();
+        ABox inner;  // union of the children's boxes, in this compound's space
         rec.kind_flags = static_cast<uint32_t>(c.kind());
         if (c.kind() == Compound::Kind::Group) {
             // the box the reference rebuilds for every ray: compound.rs:93-94
@@ -127,14 +314,24 @@ struct Flattener {
             g.n_children = static_cast<uint32_t>(c.children().size());
             rec.param = static_cast<uint32_t>(out.groups.size());
             out.groups.push_back(g);
-            for (const Shape& child : c.children()) emit(child, static_cast<int32_t>(idx), depth + 1);
+            const size_t group_slot = rec.param;
+            std::vector<BvhItem> items;
+            for (const Shape& child : c.children()) {
+                const uint32_t child_idx = static_cast<uint32_t>(out.shapes.size());
+                items.push_back(BvhItem{emit(child, static_cast<int32_t>(idx), depth + 1), child_idx});
+            }
+            for (const BvhItem& it : items) inner.merge(it.box);
+            if (opt.build_bvh && csg_depth == 0 && items.size() >= opt.bvh_min_children)
+                out.groups[group_slot].bvh_root = build_bvh(items, out.bvh_nodes);
         } else {
             rec.kind_flags |= static_cast<uint32_t>(c.operation()) << RT_FLAG_CSG_OP_SHIFT;
             rec.param = static_cast<uint32_t>(out.csgs.size());
             out.csgs.emplace_back();
             const size_t csg_slot = rec.param;
-            emit(c.children()[0], static_cast<int32_t>(idx), depth + 1);
-            emit(c.children()[1], static_cast<int32_t>(idx), depth + 1);
+            ++csg_depth;
+            inner.merge(emit(c.children()[0], static_cast<int32_t>(idx), depth + 1));
+            inner.merge(emit(c.children()[1], static_cast<int32_t>(idx), depth + 1));
+            --csg_depth;
             // l_hit table: left.includes(p) for every primitive p of the subtree (compound.rs:154, Q7)
             RtCsg cs;
             cs.op = static_cast<uint32_t>(c.operation());
@@ -147,7 +344,7 @@ struct Flattener {
         }
         rec.skip = static_cast<uint32_t>(out.shapes.size());
         out.shapes[idx] = rec;
-        return idx;
+        return inner.transformed(c.properties().transform);
     }
 };
 
@@ -167,8 +364,122 @@ RtSceneDesc FlatScene::desc() const {
     d.n_lights = static_cast<uint32_t>(lights.size()), d.lights = lights.data();
     d.n_bvh_nodes = static_cast<uint32_t>(bvh_nodes.size()), d.bvh_nodes = bvh_nodes.data();
     d.world_bvh_root = world_bvh_root;
+    d.dir_res = dir_res;
+    d.n_dir_cands = static_cast<uint32_t>(dir_cands.size()), d.dir_cands = dir_cands.data();
+    d.n_dir_entries = static_cast<uint32_t>(dir_entries.size()), d.dir_entries = dir_entries.data();
+    d.dir_cell_start = dir_cell_start.data();
     return d;
 }
+
+namespace {
+
+// a(d) = d^T Q d for a candidate
+double quad_form(const double q[6], double x, double y, double z) {
+    return q[0] * x * x + q[1] * y * y + q[2] * z * z + 2.0 * (q[3] * x * y + q[4] * x * z + q[5] * y * z);
+}
+
+// Direction of cube-map point (face, s, t), s,t in [-1,1]: faces +x -x +y -y +z -z.
+void cube_dir(int face, double s, double t, double d[3]) {
+    switch (face) {
+        case 0: d[0] = 1.0, d[1] = s, d[2] = t; break;
+        case 1: d[0] = -1.0, d[1] = s, d[2] = t; break;
+        case 2: d[0] = s, d[1] = 1.0, d[2] = t; break;
+        case 3: d[0] = s, d[1] = -1.0, d[2] = t; break;
+        case 4: d[0] = s, d[1] = t, d[2] = 1.0; break;
+        default: d[0] = s, d[1] = t, d[2] = -1.0; break;
+    }
+    const double n = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    d[0] /= n, d[1] /= n, d[2] /= n;
+}
+
+// Conservative rasterisation of {unit u : |u^T Q u| <= thr} into cube-map cells by quadtree
+// descent.  For unit u, c with r = |u - c|:  a(u) - a(c) = 2 (Qc).(u-c) + (u-c)^T Q (u-c), so
+// |a(u) - a(c)| <= 2 |Qc| r + |Q|_F r^2; a region of half-width h in (s,t) lies within chord
+// distance h*sqrt(2) of its centre.
+void raster_cand(const RtDirCand& c, double qnorm, uint32_t cand, uint32_t res, int face, uint32_t i0, uint32_t j0,
+                 uint32_t size, std::vector<std::pair<uint32_t, uint32_t>>& out) {
+    const double h = static_cast<double>(size) / static_cast<double>(res);  // half-width in s,t units
+    const double sc = -1.0 + (2.0 * i0 + size) / static_cast<double>(res);
+    const double tc = -1.0 + (2.0 * j0 + size) / static_cast<double>(res);
+    double d[3];
+    cube_dir(face, sc, tc, d);
+    const double reach = h * 1.4142135623730951 * 1.000001 + 1e-9;
+    const double gx = c.q[0] * d[0] + c.q[3] * d[1] + c.q[4] * d[2];
+    const double gy = c.q[3] * d[0] + c.q[1] * d[1] + c.q[5] * d[2];
+    const double gz = c.q[4] * d[0] + c.q[5] * d[1] + c.q[2] * d[2];
+    const double grad = std::sqrt(gx * gx + gy * gy + gz * gz);
+    const double slack = (2.0 * grad * reach + qnorm * reach * reach) * 1.000001;
+    if (std::fabs(quad_form(c.q, d[0], d[1], d[2])) > c.thr + slack) return;
+    if (size == 1) {
+        out.emplace_back((static_cast<uint32_t>(face) * res + j0) * res + i0, cand);
+        return;
+    }
+    const uint32_t half = size / 2;
+    raster_cand(c, qnorm, cand, res, face, i0, j0, half, out);
+    raster_cand(c, qnorm, cand, res, face, i0 + half, j0, half, out);
+    raster_cand(c, qnorm, cand, res, face, i0, j0 + half, half, out);
+    raster_cand(c, qnorm, cand, res, face, i0 + half, j0 + half, half, out);
+}
+
+void build_direction_index(FlatScene& f, uint32_t res) {
+    // res must be a power of two
+    uint32_t r2 = 1;
+    while (r2 * 2 <= res) r2 *= 2;
+    res = r2;
+    for (uint32_t i = 0; i < f.shapes.size(); ++i) {
+        const RtShape& s = f.shapes[i];
+        const unsigned kind = RT_KIND(s.kind_flags);
+        if (kind != RT_CYLINDER && kind != RT_CONE) continue;
+        const RtConic& cn = f.conics[s.param];
+        if (!std::isfinite(cn.minimum) && !std::isfinite(cn.maximum)) continue;  // its box is unbounded: always visited
+        // ancestors, innermost first
+        bool accelerated = f.world_bvh_root >= 0;
+        uint32_t visit = i;
+        double a[3][3];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) a[r][c] = s.inv[r * 4 + c];
+        for (int32_t p = s.parent; p >= 0; p = f.shapes[static_cast<size_t>(p)].parent) {
+            const RtShape& ps = f.shapes[static_cast<size_t>(p)];
+            if (RT_KIND(ps.kind_flags) == RT_CSG) visit = static_cast<uint32_t>(p);
+            if (RT_KIND(ps.kind_flags) == RT_GROUP && f.groups[ps.param].bvh_root >= 0) accelerated = true;
+            double m[3][3];  // a = a * inv3(parent): local direction = a_self (a_parent d)
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) {
+                    m[r][c] = 0.0;
+                    for (int k = 0; k < 3; ++k) m[r][c] += a[r][k] * ps.inv[k * 4 + c];
+                }
+            std::memcpy(a, m, sizeof a);
+        }
+        if (!accelerated) continue;
+        const double dy = kind == RT_CONE ? -1.0 : 0.0;  // a = lx^2 + dy*ly^2 + lz^2 (primitive.rs:315,323)
+        auto qij = [&](int x, int y) { return a[0][x] * a[0][y] + dy * a[1][x] * a[1][y] + a[2][x] * a[2][y]; };
+        RtDirCand c;
+        c.q[0] = qij(0, 0), c.q[1] = qij(1, 1), c.q[2] = qij(2, 2), c.q[3] = qij(0, 1), c.q[4] = qij(0, 2), c.q[5] = qij(1, 2);
+        const double qnorm = std::sqrt(c.q[0] * c.q[0] + c.q[1] * c.q[1] + c.q[2] * c.q[2] +
+                                       2.0 * (c.q[3] * c.q[3] + c.q[4] * c.q[4] + c.q[5] * c.q[5]));
+        c.thr = 1e-4 * (1.0 + 1e-5) + 1e-9 * qnorm;
+        c.shape = i;
+        c.visit = visit;
+        f.dir_cands.push_back(c);
+    }
+    if (f.dir_cands.empty()) return;
+    std::vector<std::pair<uint32_t, uint32_t>> pairs;
+    for (uint32_t k = 0; k < f.dir_cands.size(); ++k) {
+        const RtDirCand& c = f.dir_cands[k];
+        const double qnorm = (c.thr - 1e-4 * (1.0 + 1e-5)) / 1e-9;
+        for (int face = 0; face < 6; ++face) raster_cand(c, qnorm, k, res, face, 0, 0, res, pairs);
+    }
+    const size_t n_cells = static_cast<size_t>(6) * res * res;
+    f.dir_res = res;
+    f.dir_cell_start.assign(n_cells + 1, 0);
+    for (const auto& pr : pairs) ++f.dir_cell_start[pr.first + 1];
+    for (size_t c = 0; c < n_cells; ++c) f.dir_cell_start[c + 1] += f.dir_cell_start[c];
+    f.dir_entries.resize(pairs.size());
+    std::vector<uint32_t> fill(f.dir_cell_start.begin(), f.dir_cell_start.end() - 1);
+    for (const auto& pr : pairs) f.dir_entries[fill[pr.first]++] = pr.second;
+}
+
+}  // namespace
 
 FlatScene flatten(const World& world, const FlattenOptions& opt) {
     Flattener f;
@@ -179,7 +490,13 @@ FlatScene flatten(const World& world, const FlattenOptions& opt) {
         rec.intensity[0] = l.intensity.red, rec.intensity[1] = l.intensity.green, rec.intensity[2] = l.intensity.blue;
         f.out.lights.push_back(rec);
     }
-    for (const Shape& s : world.shapes()) f.emit(s, -1, 0);
+    std::vector<BvhItem> top;
+    for (const Shape& s : world.shapes()) {
+        const uint32_t idx = static_cast<uint32_t>(f.out.shapes.size());
+        top.push_back(BvhItem{f.emit(s, -1, 0), idx});
+    }
+    if (opt.build_bvh && top.size() >= opt.bvh_min_children) f.out.world_bvh_root = build_bvh(top, f.out.bvh_nodes);
+    if (opt.build_bvh && opt.dir_res > 0) build_direction_index(f.out, opt.dir_res);
     return std::move(f.out);
 }
 

@@ -24,6 +24,9 @@ struct FlatScene {
     std::vector<RtLight> lights;
     std::vector<RtBvhNode> bvh_nodes;
     int32_t world_bvh_root = -1;
+    uint32_t dir_res = 0;  // direction index over truncated conics (see RtDirCand)
+    std::vector<RtDirCand> dir_cands;
+    std::vector<uint32_t> dir_cell_start, dir_entries;
 
     RtSceneDesc desc() const;  // pointers into the vectors above; valid while *this lives unchanged
 };
@@ -31,6 +34,7 @@ struct FlatScene {
 struct FlattenOptions {
     bool build_bvh = true;        // acceleration structures over group children / world shapes
     size_t bvh_min_children = 8;  // groups smaller than this are scanned linearly
+    uint32_t dir_res = 256;       // cube-map resolution of the direction index
 };
 
 FlatScene flatten(const World& world, const FlattenOptions& opt = FlattenOptions());

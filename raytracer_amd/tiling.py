@@ -51,7 +51,7 @@ def gather_permutation(vsize, n_parts, band_rows=DEFAULT_BAND_ROWS):
 def assemble(shards, vsize, n_parts, band_rows=DEFAULT_BAND_ROWS):
     """Rebuild the frame [vsize, w, 3] from the ranks' padded shards (numpy or torch, same code)."""
     perm = gather_permutation(vsize, n_parts, band_rows)
-    if hasattr(shards[0], "device"):  # torch
+    if type(shards[0]).__module__.startswith("torch"):
         import torch
         allrows = torch.cat(list(shards), dim=0)
         return allrows.index_select(0, torch.as_tensor(perm, device=allrows.device))

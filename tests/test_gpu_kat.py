@@ -1,0 +1,158 @@
+"""GPU known answers and cross-checks, all through the C ABI: the reference's unit-test values,
+probe/color_at sweeps against the oracle on a scene holding every primitive kind, nested
+groups, CSG and all pattern kinds, the row-band entry point, device quantisation, event
+counters and the error paths."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import raytracer_amd as rt
+import scenarios
+from conftest import rel_mismatch
+from oracle import orc
+from raytracer_amd import _native as N
+from raytracer_amd import Material, Matrix, PointLight, Primitive, World, tiling
+
+pytestmark = pytest.mark.gpu
+EPS = 1e-4
+
+
+def oracle_of(world):
+    return orc.OracleWorld(world.describe())
+
+
+@pytest.mark.parametrize("case", scenarios.color_at_cases(), ids=lambda c: c[0])
+def test_color_at_known_answers(case):
+    name, world, ray, remaining, expected, _ = case
+    got = world.color_at(np.array(ray, dtype=float), remaining)
+    assert np.allclose(got, expected, atol=EPS), (name, got)
+    ref = oracle_of(world).color_at(np.array([ray], dtype=float), remaining)[0]
+    assert not rel_mismatch(got, ref).any()
+
+
+def test_mutually_reflective_surfaces_terminate():
+    world, ray = scenarios.mutually_reflective_world()
+    assert np.isfinite(world.color_at(np.array(ray, dtype=float), 5)).all()
+
+
+def test_n1_n2_and_shadows():
+    world, rays, expected = scenarios.glass_spheres_world()
+    out = world.probe(np.array(rays))
+    for row, (n1, n2) in zip(out, expected):
+        assert row[0] == 1.0 and (row[3], row[4]) == (n1, n2)
+    w = World.default()
+    # is_shadowed(point): probe reports it for the over_point of a hit, so aim rays at planes through the points
+    ow = oracle_of(w)
+    rays = scenarios.random_rays(2000, 11)
+    assert np.array_equal(w.probe(rays)[:, 15], ow.probe(rays)[:, 15])
+
+
+@pytest.mark.parametrize("which", ["with_shadowless", "all_cast_shadows"])
+def test_probe_and_color_sweep_on_every_primitive_kind(which):
+    with_ghost, without_ghost = scenarios.primitive_zoo()
+    world = with_ghost if which == "with_shadowless" else without_ghost
+    ow = oracle_of(world)
+    rays = scenarios.random_rays(20000, 5)
+    got, ref = world.probe(rays), ow.probe(rays)
+    assert np.array_equal(got[:, [0, 2, 3, 4, 5, 15]], ref[:, [0, 2, 3, 4, 5, 15]])   # hit, shape, n1, n2, inside, shadow
+    assert not rel_mismatch(got, ref, 1e-12, 1e-15).any()
+    assert (got[:, 0] == 1).mean() > 0.5
+    col, cref = world.color_at(rays, 5), ow.color_at(rays, 5)
+    bad = rel_mismatch(col, cref).any(axis=1)
+    assert bad.sum() == 0, f"{bad.sum()} of {len(rays)} rays beyond 1e-9 relative"
+
+
+def test_event_counters_match_oracle_ray_counts():
+    for name in ("glass_bubble", "csg", "cover"):
+        world, cam = rt.exercise(name, 160, 90)
+        _, st = cam.render(world, stats=True)
+        _, counts = oracle_of(world).render(cam)
+        assert [st.rays_primary, st.rays_shadow, st.rays_reflect, st.rays_refract] == counts, name
+        assert st.kernel_ms > 0 and st.status_flags == 0
+
+
+def test_row_bands_device_output_and_quantize():
+    import torch
+    world, cam = rt.exercise("room", 200, 77)
+    full = cam.render(world).pixels
+    scene = rt.DeviceScene(world.flatten())
+    cd = cam.desc()
+    n_parts, band = 3, 8
+    slots = tiling.padded_local_rows(77, n_parts, band)
+    shards = []
+    for part in range(n_parts):
+        buf = torch.full((slots, 200, 3), float("nan"), dtype=torch.float64, device="cuda")
+        scene.render_rows(cd, 5, part, n_parts, band, tiling.n_local_rows(77, part, n_parts, band), buf.data_ptr(),
+                          torch.cuda.current_stream().cuda_stream)
+        shards.append(buf)
+    torch.cuda.synchronize()
+    scene.status()
+    frame = tiling.assemble(shards, 77, n_parts, band)
+    assert np.array_equal(frame.cpu().numpy(), full)
+    q = torch.empty(frame.numel(), dtype=torch.uint8, device="cuda")
+    frame = frame.contiguous()
+    N.check(N.hip.rt_hip_quantize(C.c_void_p(frame.data_ptr()), frame.numel(), C.c_void_p(q.data_ptr()),
+                                  C.c_void_p(torch.cuda.current_stream().cuda_stream)), "rt_hip_quantize")
+    torch.cuda.synchronize()
+    assert np.array_equal(q.cpu().numpy().reshape(77, 200, 3), orc.quantize(full))
+    special = torch.tensor([float("nan"), -1.0, 2.0, 0.5, 0.498039215686, 1.0, -0.0], dtype=torch.float64, device="cuda")
+    q = torch.empty(7, dtype=torch.uint8, device="cuda")
+    N.check(N.hip.rt_hip_quantize(C.c_void_p(special.data_ptr()), 7, C.c_void_p(q.data_ptr()), None), "quantize")
+    torch.cuda.synchronize()
+    assert np.array_equal(q.cpu().numpy(), orc.quantize(special.cpu().numpy()))
+
+
+def test_acceleration_structure_never_changes_the_image():
+    import torch
+    world, cam = rt.synthetic(192, 108, 3000)
+    cd = cam.desc()
+    frames = []
+    for bvh in (False, True):
+        scene = rt.DeviceScene(world.flatten(build_bvh=bvh))
+        buf = torch.zeros((108, 192, 3), dtype=torch.float64, device="cuda")
+        scene.render_rows(cd, 5, 0, 1, 108, 108, buf.data_ptr())
+        torch.cuda.synchronize()
+        scene.status()
+        frames.append(buf.cpu().numpy())
+    assert np.array_equal(frames[0], frames[1])
+    world, cam = rt.exercise("teapot", 160, 90)
+    a = cam.render(world).pixels
+    scene = rt.DeviceScene(world.flatten(build_bvh=False))
+    buf = torch.zeros((90, 160, 3), dtype=torch.float64, device="cuda")
+    scene.render_rows(cam.desc(), 5, 0, 1, 90, 90, buf.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(a, buf.cpu().numpy())
+
+
+def test_list_overflow_is_reported_not_hidden():
+    glass = Material(transparency=1.0, refractive_index=1.5)
+    shells = [Primitive.new_sphere().with_transform(Matrix.scaling(1 + 0.01 * k, 1 + 0.01 * k, 1 + 0.01 * k))
+              .with_material(glass) for k in range(140)]
+    world = World(shells, [PointLight((-10, 10, -10), (1, 1, 1))])
+    with pytest.raises(rt.RenderError) as e:
+        world.color_at(np.array([0, 0, 0, 0, 0, 1.0]), 2)
+    assert e.value.code == N.RT_ERR_LIST_OVERFLOW
+    # the same scene within the capacity renders and matches
+    world = World(shells[:40], [PointLight((-10, 10, -10), (1, 1, 1))])
+    ray = np.array([[0, 0, 0, 0, 0, 1.0], [0, 0.5, -5, 0, 0, 1.0]])
+    assert not rel_mismatch(world.color_at(ray, 3), oracle_of(world).color_at(ray, 3)).any()
+
+
+def test_empty_and_degenerate_inputs():
+    assert np.array_equal(World.empty().color_at(np.array([0, 0, -5, 0, 0, 1.0])), (0, 0, 0))
+    img = rt.Camera(5, 3, 1.0).render(World.empty()).pixels
+    assert img.shape == (3, 5, 3) and (img == 0).all()
+    w = World.default()
+    assert w.color_at(np.zeros((0, 6))).shape == (0, 3)
+    one = rt.Camera(1, 1, 0.5).render(w).pixels
+    ref, _ = oracle_of(w).render(rt.Camera(1, 1, 0.5))
+    assert np.array_equal(one, ref)
+    # a light-less world shades to black (Sum folds from BLACK, color.rs:42-46)
+    dark = World([Primitive.new_sphere()], [])
+    assert np.array_equal(dark.color_at(np.array([0, 0, -5, 0, 0, 1.0])), (0, 0, 0))
+    # empty group and a group of one
+    g = rt.Compound.new_group([])
+    w2 = World([g, rt.Compound.new_group([Primitive.new_sphere()])], [PointLight((-10, 10, -10), (1, 1, 1))])
+    r = np.array([[0, 0, -5, 0, 0, 1.0]])
+    assert not rel_mismatch(w2.color_at(r), oracle_of(w2).color_at(r)).any()

@@ -1,0 +1,199 @@
+"""Host side of the boundary, on CPU: scene flattening, table validation, PPM writer, OBJ
+parser, row-band tiling and the FLOP budget."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import raytracer_amd as rt
+import scenarios
+from oracle import orc
+from raytracer_amd import _native as N
+from raytracer_amd import flops, tiling
+from raytracer_amd import Conic, Material, Matrix, Operation, Primitive, World
+
+
+def create(desc):
+    p = C.c_void_p()
+    rc = N.hip.rt_hip_scene_create(desc, C.byref(p))
+    if rc == 0:
+        N.hip.rt_hip_scene_destroy(p)
+    return rc
+
+
+def test_flatten_is_preorder_with_skip_links():
+    world, _ = scenarios.primitive_zoo()
+    flat = world.flatten()
+    d = flat.desc.contents
+    shapes = [d.shapes[i] for i in range(d.n_shapes)]
+    kinds = [s.kind_flags & 0xff for s in shapes]
+    assert kinds.count(N.RT_GROUP) == 2 and kinds.count(N.RT_CSG) == 2
+    for i, s in enumerate(shapes):
+        assert i < s.skip <= d.n_shapes
+        if kinds[i] <= N.RT_SMOOTH_TRIANGLE:
+            assert s.skip == i + 1 and s.material < d.n_materials
+        for c in range(i + 1, s.skip):
+            assert shapes[c].depth > s.depth
+    # oracle numbers its nodes in the same depth-first pre-order
+    assert orc.OracleWorld(world.describe()).num_nodes == d.n_shapes
+    # a valid scene passes validation; with no GPU the next step reports NO_DEVICE, never "ok"
+    assert create(flat.desc) in (N.RT_OK, N.RT_ERR_NO_DEVICE)
+
+
+def test_lhit_table_matches_oracle_includes():
+    world, _ = scenarios.primitive_zoo()
+    flat = world.flatten()
+    d = flat.desc.contents
+    ow = orc.OracleWorld(world.describe())
+    for i in range(d.n_shapes):
+        s = d.shapes[i]
+        if (s.kind_flags & 0xff) == N.RT_CSG:
+            c = d.csgs[s.param]
+            for p in range(i + 1, s.skip):
+                is_prim = (d.shapes[p].kind_flags & 0xff) <= N.RT_SMOOTH_TRIANGLE
+                want = ow.csg_includes_left(i, p) if is_prim else 0
+                assert d.lhit[c.lhit_offset + p - i - 1] == want
+
+
+def test_group_gate_box_matches_oracle_bounds():
+    s = Primitive.new_sphere().with_transform(Matrix.translation(2, 5, -3))
+    g = rt.Compound.new_group([s, Primitive.new_cube()])          # untransformed group: gate == stored bounds
+    world = World([g], [])
+    flat = world.flatten()
+    d = flat.desc.contents
+    mn, mx = orc.OracleWorld(world.describe()).bounds(0)
+    assert np.array_equal(np.array(list(d.groups[0].bmin)), mn)
+    assert np.array_equal(np.array(list(d.groups[0].bmax)), mx)
+
+
+@pytest.mark.parametrize("mutate,code", [
+    (lambda d: setattr(d.shapes[0], "skip", 0), N.RT_ERR_INVALID_SCENE),
+    (lambda d: setattr(d.shapes[0], "kind_flags", 77), N.RT_ERR_INVALID_SCENE),
+    (lambda d: setattr(d.shapes[1], "material", 10 ** 6), N.RT_ERR_INVALID_SCENE),
+    (lambda d: setattr(d.shapes[1], "parent", 5), N.RT_ERR_INVALID_SCENE),
+    (lambda d: setattr(d.materials[0], "pattern", 10 ** 6), N.RT_ERR_INVALID_SCENE),
+    (lambda d: setattr(d, "world_bvh_root", 10 ** 6), N.RT_ERR_INVALID_SCENE),
+])
+def test_malformed_tables_are_rejected(mutate, code):
+    world, _ = scenarios.primitive_zoo()
+    flat = world.flatten()
+    mutate(flat.desc.contents)
+    assert create(flat.desc) == code
+
+
+def test_bvh_links_only_go_forward():
+    world, _ = rt.synthetic(64, 36, 500)
+    flat = world.flatten(build_bvh=True)
+    d = flat.desc.contents
+    assert d.n_bvh_nodes > 0
+    leaves = set()
+    for k in range(d.n_bvh_nodes):
+        nd = d.bvh_nodes[k]
+        assert nd.miss == -1 or k < nd.miss < d.n_bvh_nodes
+        if nd.shape >= 0:
+            leaves.add(nd.shape)
+            bmin, bmax = np.array(list(nd.bmin)), np.array(list(nd.bmax))
+            assert (bmin <= bmax).all()
+    # every shape that sits directly under a BVH-accelerated level is named by exactly one leaf
+    assert len(leaves) > 400
+    assert create(flat.desc) in (N.RT_OK, N.RT_ERR_NO_DEVICE)
+
+
+def test_nesting_deeper_than_the_stack_is_rejected():
+    s = Primitive.new_sphere()
+    for _ in range(N.RT_MAX_NEST + 1):
+        s = rt.Compound.new_group([s])
+    flat = World([s], []).flatten()
+    assert create(flat.desc) == N.RT_ERR_NEST_TOO_DEEP
+
+
+def test_depth_and_argument_checks():
+    cd = rt.Camera(8, 8, 1.0).desc()
+    flat = World.default().flatten()
+    out = np.zeros(8 * 8 * 3)
+    rc = N.hip.rt_hip_render(flat.desc, C.byref(cd), N.RT_MAX_DEPTH + 1, out.ctypes.data_as(N.c_double_p), None)
+    assert rc == N.RT_ERR_DEPTH
+    assert N.hip.rt_hip_render(flat.desc, None, 5, out.ctypes.data_as(N.c_double_p), None) == N.RT_ERR_INVALID_ARG
+    assert N.hip.rt_hip_scene_create(None, None) == N.RT_ERR_INVALID_ARG
+
+
+def test_singular_transform_raises_like_the_reference_asserts():  # matrix.rs:94
+    with pytest.raises(RuntimeError):
+        Primitive.new_sphere().with_transform(np.zeros((4, 4)))
+
+
+def test_canvas_ppm_layout():  # canvas.rs:125-203
+    c = rt.Canvas(5, 3)
+    c.write_pixel(0, 0, (1.5, 0, 0)); c.write_pixel(2, 1, (0, 0.5, 0)); c.write_pixel(4, 2, (-0.5, 0, 1))
+    lines = c.to_ppm().decode().split("\n")
+    assert lines[:3] == ["P3", "5 3", "255"]
+    assert lines[3] == "255 0 0 0 0 0 0 0 0 0 0 0 0 0 0"
+    assert lines[4] == "0 0 0 0 0 0 0 128 0 0 0 0 0 0 0"
+    assert lines[5] == "0 0 0 0 0 0 0 0 0 0 0 0 0 0 255"
+    wide = rt.Canvas(10, 2, np.tile(np.array([1.0, 0.8, 0.6]), (2, 10, 1)))
+    text = wide.to_ppm().decode()
+    assert all(len(l) <= 70 for l in text.split("\n")) and text.endswith("\n")
+    assert text == orc.to_ppm(wide.pixels).decode()
+    rng = np.random.default_rng(3)
+    px = rng.uniform(-0.2, 1.2, size=(7, 33, 3))
+    assert rt.Canvas(33, 7, px).to_ppm() == orc.to_ppm(px)
+    assert np.array_equal(rt.Canvas(33, 7, px).quantized(), orc.quantize(px))
+
+
+def test_obj_parser():  # obj.rs:187-350
+    with pytest.raises(RuntimeError, match="no shapes found"):   # obj.rs:47: gibberish alone yields no shape
+        rt.obj.parse_string("There was a young lady named Bright\nwho traveled much faster than light.\n")
+    shape, ignored = rt.obj.parse_string("gibberish line\nv 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\nanother one\n")
+    assert ignored == 2
+    text = "v -1 1 0\nv -1 0 0\nv 1 0 0\nv 1 1 0\nv 0 2 0\n\nf 1 2 3 4 5\n"
+    shape, _ = rt.obj.parse_string(text)
+    keep = World([shape], []).flatten()
+    flat = keep.desc.contents
+    assert flat.n_triangles == 3                                     # fan triangulation (obj.rs:132-140)
+    t = flat.triangles[1]
+    assert list(t.p1) == [-1, 1, 0] and list(t.e1) == [2, -1, 0] and list(t.e2) == [2, 0, 0]
+    text = "v 0 1 0\nv -1 0 0\nv 1 0 0\nvn -1 0 0\nvn 1 0 0\nvn 0 1 0\nf 1//3 2//1 3//2\nf 1/0/3 2/102/1 3/14/2\n"
+    shape, _ = rt.obj.parse_string(text)
+    keep = World([shape], []).flatten()
+    flat = keep.desc.contents
+    assert flat.n_triangles == 2
+    assert list(flat.triangles[0].n1) == [0, 1, 0] and list(flat.triangles[0].n2) == [-1, 0, 0]
+    text = "v -1 1 0\nv -1 0 0\nv 1 0 0\nv 1 1 0\ng FirstGroup\nf 1 2 3\ng SecondGroup\nf 1 3 4\n"
+    shape, _ = rt.obj.parse_string(text)
+    assert shape.kind == N.RT_GROUP and len(shape.children()) == 2
+
+
+def test_teapot_obj_loads():
+    world, _ = rt.exercise("teapot", 32, 18)
+    flat = world.flatten()
+    d = flat.desc.contents
+    assert d.n_triangles == 9216 and d.n_shapes == 9216 + 2
+
+
+def test_tiling_round_trip():
+    for vsize, n_parts, band in [(2160, 1, 16), (2160, 8, 16), (1080, 3, 16), (37, 4, 8), (5, 8, 16)]:
+        rows = [tiling.image_rows(vsize, p, n_parts, band) for p in range(n_parts)]
+        seen = np.concatenate([r[r >= 0] for r in rows])
+        assert sorted(seen) == list(range(vsize))
+        slots = tiling.padded_local_rows(vsize, n_parts, band)
+        frame = np.arange(vsize * 4 * 3, dtype=float).reshape(vsize, 4, 3)
+        shards = []
+        for p in range(n_parts):
+            r = tiling.image_rows(vsize, p, n_parts, band, n_slots=slots)
+            s = np.full((slots, 4, 3), np.nan)
+            s[r >= 0] = frame[r[r >= 0]]
+            shards.append(s)
+        assert np.array_equal(tiling.assemble(shards, vsize, n_parts, band), frame)
+
+
+def test_flop_budget():
+    stats = {k: 0 for k in ("rays_primary", "rays_shadow", "rays_reflect", "rays_refract", "ray_transforms",
+                            "group_gates", "bvh_box_tests", "hits_shaded", "normal_levels", "lightings", "pow_calls",
+                            "pattern_nodes", "container_passes", "list_entries", "schlicks")}
+    stats["prim_tests"] = [0] * 7
+    assert flops.algorithmic_flops(stats) == 0
+    # SURVEY.md 8(d) worked example: a config-1 primary ray that hits a sphere and is lit, about 685 FLOPs
+    stats.update(rays_primary=1, rays_shadow=1, ray_transforms=8, hits_shaded=1, normal_levels=2, lightings=1, pow_calls=1)
+    stats["prim_tests"] = [6, 2, 0, 0, 0, 0, 0]
+    assert 600 < flops.algorithmic_flops(stats) < 800
+    assert flops.total_rays(stats) == 2

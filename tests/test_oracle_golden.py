@@ -1,0 +1,78 @@
+"""Pins the CPU oracle against the reference's golden renders.
+
+* tests/golden/shading.ppm is the reference's own output of exercises/shading.rs
+  (images/ppm/shading.ppm): byte-exact, PPM text layout included.
+* tests/golden/<scene>.png are the reference's 2048x1080 renders (images/png/*.png, lossless
+  stand-ins for the PPMs missing from the mount).  Bar: 8-bit values identical except on
+  <= 0.1 % of pixels (north_star); in practice a handful of seam pixels.
+* pattern.png: pixels whose primary hit is the Perturb sphere are excluded -- the reference
+  calls the `noise` crate, which is not in the tree ("parity unpinned" for Perturb).
+Heavy scenes are compared on a row subsample so the CPU suite stays within minutes.
+"""
+import os
+
+import numpy as np
+import pytest
+from PIL import Image
+
+import raytracer_amd as rt
+from oracle import orc
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# scene -> row step of the comparison (1 = every row of the 2048x1080 golden)
+ROW_STEP = {"plane": 1, "scene": 1, "pattern": 1, "glass_bubble": 1, "hexagon": 1, "csg": 4, "cover": 2, "room": 2,
+            "teapot": 24}
+
+
+def golden_rows(name, first, step):
+    return np.array(Image.open(os.path.join(GOLDEN, f"{name}.png")).convert("RGB"))[first::step]
+
+
+def test_shading_ppm_is_byte_exact():
+    img = orc.exercise_shading()
+    with open(os.path.join(GOLDEN, "shading.ppm"), "rb") as f:
+        golden = f.read()
+    assert orc.to_ppm(img) == golden
+    # the host mirror's Canvas writer produces the same bytes (canvas.rs:46-83)
+    assert rt.Canvas(500, 500, img).to_ppm() == golden
+
+
+@pytest.mark.parametrize("name", list(ROW_STEP))
+def test_oracle_matches_golden_png(name):
+    step = ROW_STEP[name]
+    first = step // 2
+    world, cam = rt.exercise(name)
+    ow = orc.OracleWorld(world.describe())
+    img, _ = ow.render(cam, rows=(first, cam.v_size, step))
+    got = orc.quantize(img)[first::step]
+    want = golden_rows(name, first, step)
+    diff = np.abs(got.astype(int) - want.astype(int)).max(axis=2)
+    considered = np.ones(diff.shape, dtype=bool)
+    if name == "pattern":
+        # mask = pixels whose primary ray hits the middle (Perturb) sphere, shape id 3
+        ys = np.arange(first, cam.v_size, step)
+        xs = np.arange(cam.h_size)
+        cd = cam.desc()
+        inv = np.array(list(cd.inv)).reshape(4, 4)
+        wx = cd.half_width - (xs + 0.5) * cd.pixel_size
+        wy = cd.half_height - (ys + 0.5) * cd.pixel_size
+        px = np.stack(np.broadcast_arrays(wx[None, :], wy[:, None], -1.0, 1.0), axis=-1) @ inv.T
+        origin = inv @ np.array([0.0, 0.0, 0.0, 1.0])
+        d = px[..., :3] - origin[:3]
+        d /= np.linalg.norm(d, axis=-1, keepdims=True)
+        rays = np.concatenate([np.broadcast_to(origin[:3], d.shape), d], axis=-1).reshape(-1, 6)
+        probe = ow.probe(rays).reshape(len(ys), len(xs), 16)
+        perturbed = (probe[..., 0] == 1.0) & (probe[..., 2] == 3.0)
+        assert 0.10 < perturbed.mean() < 0.20  # SURVEY: 333 111 px = 15 %
+        # one-pixel dilation so that float noise in this mask's rays cannot leak an edge pixel
+        grown = perturbed.copy()
+        grown[1:] |= perturbed[:-1]; grown[:-1] |= perturbed[1:]
+        grown[:, 1:] |= perturbed[:, :-1]; grown[:, :-1] |= perturbed[:, 1:]
+        considered = ~grown
+    n = int(considered.sum())
+    differ = int(((diff > 0) & considered).sum())
+    beyond_lsb = int(((diff > 1) & considered).sum())
+    print(f"{name}: {differ}/{n} pixels differ from the golden render ({beyond_lsb} by more than 1 LSB)")
+    assert differ <= 1e-3 * n
+    assert beyond_lsb <= 16  # isolated seam/edge coin flips only (Q13)
