@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--primitives", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--print-stats", action="store_true", help="event counters of one frame to stderr")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle sample")
     return ap.parse_args()
 
@@ -102,6 +103,8 @@ def main():
     import ctypes as C
     st = N.RtStats.from_buffer_copy(bytes(d_stats.cpu().numpy()[:C.sizeof(N.RtStats)]))
     stats = st.as_dict()
+    if args.print_stats and rank == 0:
+        print(json.dumps(stats), file=sys.stderr)
     my_rays = flops.total_rays(stats)
     my_flops = flops.algorithmic_flops(stats)
     tot = torch.tensor([my_rays, my_flops], dtype=torch.float64, device=dev)

@@ -19,6 +19,10 @@
 
 using namespace rtd;
 
+#ifndef RT_WAVES_PER_SIMD
+#define RT_WAVES_PER_SIMD 2  // register budget of the tracing kernels: 512 / this many VGPR+AGPR per lane
+#endif
+
 // ============================================================== kernels ===
 namespace {
 
@@ -42,9 +46,10 @@ __device__ void flush_stats(Ctx<STATS>& cx, RtStats* __restrict__ stats, unsigne
 }
 
 template <bool STATS>
-__global__ __launch_bounds__(256) void render_kernel(SceneDev S, RtCameraDesc cam, int depth, RowMap rows,
+__global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const SceneDev* __restrict__ scene, RtCameraDesc cam, int depth, RowMap rows,
                                                      double* __restrict__ out, RtStats* __restrict__ stats,
                                                      unsigned* __restrict__ status) {
+    const SceneDev& S = *scene;  // uniform pointer: table bases come through the scalar cache
     // 16x16 pixels per block, one 8x8 tile per wave: neighbouring pixels share a wave
     const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const unsigned x = blockIdx.x * 16u + (wave & 1u) * 8u + (lane & 7u);
@@ -75,9 +80,10 @@ __global__ __launch_bounds__(256) void render_kernel(SceneDev S, RtCameraDesc ca
     flush_stats(cx, stats, status);
 }
 
-__global__ __launch_bounds__(256) void color_at_kernel(SceneDev S, const double* __restrict__ rays, unsigned n,
-                                                       int depth, double* __restrict__ out,
-                                                       unsigned* __restrict__ status) {
+__global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void color_at_kernel(const SceneDev* __restrict__ scene,
+                                                       const double* __restrict__ rays, unsigned n, int depth,
+                                                       double* __restrict__ out, unsigned* __restrict__ status) {
+    const SceneDev& S = *scene;
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     Ctx<false> cx;
     cx.status = 0;
@@ -94,8 +100,10 @@ __global__ __launch_bounds__(256) void color_at_kernel(SceneDev S, const double*
     flush_stats(cx, nullptr, status);
 }
 
-__global__ __launch_bounds__(256) void probe_kernel(SceneDev S, const double* __restrict__ rays, unsigned n,
-                                                    double* __restrict__ out, unsigned* __restrict__ status) {
+__global__ __launch_bounds__(256) void probe_kernel(const SceneDev* __restrict__ scene, const double* __restrict__ rays,
+                                                    unsigned n, double* __restrict__ out,
+                                                    unsigned* __restrict__ status) {
+    const SceneDev& S = *scene;
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     Ctx<false> cx;
     cx.status = 0;
@@ -281,6 +289,11 @@ int validate(const RtSceneDesc& d, uint32_t* flags_out) {
         if (nd.shape < 0 && k + 1 >= d.n_bvh_nodes) return RT_ERR_INVALID_SCENE;  // inner node needs a successor
     }
     if (d.world_bvh_root < -1 || d.world_bvh_root >= (int32_t)d.n_bvh_nodes) return RT_ERR_INVALID_SCENE;
+    if (d.world_bvh_root < 0) {
+        bool flat = true;
+        for (uint32_t i = 0; i < d.n_shapes; ++i) flat = flat && RT_KIND(d.shapes[i].kind_flags) <= RT_SMOOTH_TRIANGLE;
+        if (flat) flags |= RT_SCENE_FLAT;
+    }
     // direction index: offsets monotone and inside the entry list, entries name candidates,
     // candidates name a conic and the shape to evaluate for it (itself or an enclosing CSG)
     if (d.dir_res != 0) {
@@ -309,7 +322,8 @@ int validate(const RtSceneDesc& d, uint32_t* flags_out) {
 }  // namespace
 
 struct RtScene {
-    SceneDev dev;
+    SceneDev dev;      // host copy of the table pointers
+    SceneDev* d_dev;   // the same record in device memory: what the kernels read
     unsigned* d_status;
     int device;
     std::vector<void*> allocations;
@@ -343,10 +357,10 @@ int launch_render(const RtScene* scene, const RtCameraDesc* cam, uint32_t depth,
     const dim3 grid((cam->hsize + 15u) / 16u, (rows.n_local_rows + 15u) / 16u);
     if (grid.y > 65535u * 16u) return RT_ERR_INVALID_ARG;
     if (d_stats)
-        hipLaunchKernelGGL(render_kernel<true>, grid, block, 0, stream, scene->dev, *cam, (int)depth, rows, d_out, d_stats,
+        hipLaunchKernelGGL(render_kernel<true>, grid, block, 0, stream, scene->d_dev, *cam, (int)depth, rows, d_out, d_stats,
                            scene->d_status);
     else
-        hipLaunchKernelGGL(render_kernel<false>, grid, block, 0, stream, scene->dev, *cam, (int)depth, rows, d_out,
+        hipLaunchKernelGGL(render_kernel<false>, grid, block, 0, stream, scene->d_dev, *cam, (int)depth, rows, d_out,
                            (RtStats*)nullptr, scene->d_status);
     HIP_TRY(hipGetLastError());
     return RT_OK;
@@ -410,6 +424,7 @@ int rt_hip_scene_create(const RtSceneDesc* desc, RtScene** out) {
     RtScene* s = new RtScene();
     std::memset(&s->dev, 0, sizeof s->dev);
     s->d_status = nullptr;
+    s->d_dev = nullptr;
     s->device = g_device;
     int rc = RT_OK;
     auto up = [&](auto* src, size_t n, auto** dst) {
@@ -460,6 +475,20 @@ int rt_hip_scene_create(const RtSceneDesc* desc, RtScene** out) {
     s->dev.n_lights = desc->n_lights;
     s->dev.world_bvh_root = desc->world_bvh_root;
     s->dev.flags = flags;
+    {
+        const hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->d_dev), sizeof(SceneDev));
+        if (e != hipSuccess) {
+            rc = hip_fail(e, "hipMalloc(scene record)");
+        } else {
+            s->allocations.push_back(s->d_dev);
+            const hipError_t e2 = hipMemcpy(s->d_dev, &s->dev, sizeof(SceneDev), hipMemcpyHostToDevice);
+            if (e2 != hipSuccess) rc = hip_fail(e2, "hipMemcpy(scene record)");
+        }
+    }
+    if (rc != RT_OK) {
+        rt_hip_scene_destroy(s);
+        return rc;
+    }
     *out = s;
     return RT_OK;
 }
@@ -539,7 +568,7 @@ int rt_hip_color_at(const RtScene* scene, const double* rays, uint32_t n, uint32
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_rays), (size_t)n * 6u * sizeof(double)));
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_out), (size_t)n * 3u * sizeof(double)));
         HIP_TRY(hipMemcpy(d_rays, rays, (size_t)n * 6u * sizeof(double), hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(color_at_kernel, dim3((n + 255u) / 256u), dim3(256), 0, nullptr, scene->dev, d_rays, n,
+        hipLaunchKernelGGL(color_at_kernel, dim3((n + 255u) / 256u), dim3(256), 0, nullptr, scene->d_dev, d_rays, n,
                            (int)depth, d_out, scene->d_status);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpy(out_rgb, d_out, (size_t)n * 3u * sizeof(double), hipMemcpyDeviceToHost));
@@ -559,7 +588,7 @@ int rt_hip_probe(const RtScene* scene, const double* rays, uint32_t n, double* o
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_rays), (size_t)n * 6u * sizeof(double)));
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_out), (size_t)n * 16u * sizeof(double)));
         HIP_TRY(hipMemcpy(d_rays, rays, (size_t)n * 6u * sizeof(double), hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(probe_kernel, dim3((n + 255u) / 256u), dim3(256), 0, nullptr, scene->dev, d_rays, n, d_out,
+        hipLaunchKernelGGL(probe_kernel, dim3((n + 255u) / 256u), dim3(256), 0, nullptr, scene->d_dev, d_rays, n, d_out,
                            scene->d_status);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpy(out, d_out, (size_t)n * 16u * sizeof(double), hipMemcpyDeviceToHost));

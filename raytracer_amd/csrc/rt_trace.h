@@ -28,8 +28,16 @@
 namespace rtd {
 
 #define RT_STACK (RT_MAX_NEST + 2)
+// Rarely taken, register-hungry paths are real calls so that they do not inflate the
+// register budget (and so the occupancy) of the traversal loop they are reached from.
+#ifndef RT_COLD_CALLS
+#define RT_DEV_COLD __device__ __forceinline__
+#else
+#define RT_DEV_COLD __device__ __noinline__
+#endif
 #define RT_CONTAINERS_CAP RT_LIST_CAP
 #define RT_SCENE_HAS_SHADOWLESS 1u
+#define RT_SCENE_FLAT 2u  // primitives only at world level, no acceleration structure
 
 struct SceneDev {
     const RtShape* __restrict__ shapes;
@@ -341,7 +349,7 @@ RT_DEV int list_eval_core(const SceneDev& S, Scratch& W, int begin, int end, int
 
 // A compound subtree evaluated on its own (CSG nodes met by the streaming traversal).
 template <bool STATS>
-RT_DEV int list_eval(const SceneDev& S, Scratch& W, int begin, int end, int level0, int base0, double bound,
+RT_DEV_COLD int list_eval(const SceneDev& S, Scratch& W, int begin, int end, int level0, int base0, double bound,
                      Ctx<STATS>& cx) {
     return list_eval_core<false>(S, W, begin, end, level0, base0, base0, bound, cx);
 }
@@ -378,32 +386,33 @@ RT_DEV int ancestor_chain(const SceneDev& S, int parent, int* chain) {  // inner
 
 // One non-group shape `s` met with the ray of its enclosing level (`level` = its nesting depth):
 // a primitive is intersected, a CSG node is materialised through list_eval; the surviving hits go
-// to the closest-hit reduction or the shadow test.  Returns true when a shadow hit was found.
-template <bool SHADOW, bool STATS>
+// to the closest-hit reduction or, for a shadow feeler, to the "anything before the light" test.
+// Returns true when a shadow hit was found.
+template <bool STATS>
 RT_DEV bool process_leaf(const SceneDev& S, Scratch& W, int s, const RtShape* __restrict__ sh, unsigned kf,
-                         const Ray& ray, int level, double limit, Best& best, Ctx<STATS>& cx) {
+                         const Ray& ray, int level, bool shadow, double limit, Best& best, Ctx<STATS>& cx) {
     if (RT_KIND(kf) <= RT_SMOOTH_TRIANGLE) {
-        if (SHADOW && !(kf & RT_FLAG_HAS_SHADOW)) return false;
+        if (shadow && !(kf & RT_FLAG_HAS_SHADOW)) return false;
         PrimHits h;
         prim_intersect(S, sh, kf, ray, h, cx);
+        bool found = false;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if ((h.keep >> k) & 1u) {
-                if (SHADOW) {
-                    if (h.t[k] >= 0.0 && h.t[k] < limit) return true;
-                } else {
+                if (shadow)
+                    found = found || (h.t[k] >= 0.0 && h.t[k] < limit);
+                else
                     offer(best, h.t[k], s);
-                }
             }
         }
-        return false;
+        return found;
     }
     W.rays[level] = ray;
     const int n = list_eval(S, W, s, (int)sh->skip, level, 0, __builtin_inf(), cx);
     for (int j = 0; j < n; ++j) {
         const double t = W.lt[j];
         const int id = (int)W.lid[j];
-        if (SHADOW) {
+        if (shadow) {
             if ((S.shapes[id].kind_flags & RT_FLAG_HAS_SHADOW) && t >= 0.0 && t < limit) return true;
         } else {
             offer(best, t, id);
@@ -476,7 +485,7 @@ RT_DEV bool for_each_direction_candidate(const SceneDev& S, const Ray& ray, Ctx<
 
 // World::intersections (world.rs:45-53) as a sorted list at W.lt/lid[0, n), cut at t <= bound.
 template <bool STATS>
-RT_DEV int world_list(const SceneDev& S, Scratch& W, const Ray& ray, double bound, Ctx<STATS>& cx) {
+RT_DEV_COLD int world_list(const SceneDev& S, Scratch& W, const Ray& ray, double bound, Ctx<STATS>& cx) {
     int top = 0;
     if (S.dir_res != 0u) {
         for_each_direction_candidate(S, ray, cx, [&](int node, const RtShape* __restrict__ sh, const Ray& r, int n) {
@@ -500,10 +509,37 @@ RT_DEV int world_list(const SceneDev& S, Scratch& W, const Ray& ray, double boun
     return list_eval_core<true>(S, W, 0, (int)S.n_shapes, 0, 0, top, bound, cx);
 }
 
-// SHADOW == false: closest hit into `best`.  SHADOW == true: returns true as soon as a
-// shadow-casting primitive is met at 0 <= t < limit (world.rs:85-96).
-template <bool SHADOW, bool STATS>
-RT_DEV bool traverse(const SceneDev& S, Scratch& W, const Ray& world_ray, double limit, Best& best, Ctx<STATS>& cx) {
+// One ray against the world.  shadow == false: closest hit into `best` (world.rs:32-36,
+// intersection.rs:154-158).  shadow == true: returns true as soon as a shadow-casting
+// primitive is met at 0 <= t < limit (world.rs:85-96).  Colour rays and shadow feelers share
+// this one loop so that the lanes of a wave stay together whatever each one is tracing.
+template <bool STATS>
+RT_DEV bool trace(const SceneDev& S, Scratch& W, const Ray& world_ray, bool shadow, double limit, Best& best,
+                  Ctx<STATS>& cx) {
+    if (S.flags & RT_SCENE_FLAT) {
+        // only primitives, no acceleration structure: every lane walks the same shape sequence,
+        // so the records are fetched once per wave through the scalar cache
+        bool found = false;
+        const int n = (int)S.n_shapes;
+        for (int s = 0; s < n; ++s) {
+            const RtShape* __restrict__ sh = S.shapes + s;
+            const unsigned kf = sh->kind_flags;
+            if (shadow && !(kf & RT_FLAG_HAS_SHADOW)) continue;
+            PrimHits h;
+            prim_intersect(S, sh, kf, world_ray, h, cx);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if ((h.keep >> k) & 1u) {
+                    if (shadow)
+                        found = found || (h.t[k] >= 0.0 && h.t[k] < limit);
+                    else
+                        offer(best, h.t[k], s);
+                }
+            }
+            if (__builtin_amdgcn_ballot_w64(!found) == 0ull) break;  // every live lane is already in shadow
+        }
+        return found;
+    }
     int level = 0;
     Ray ray = world_ray;
     bool bvh = S.world_bvh_root >= 0;
@@ -512,27 +548,30 @@ RT_DEV bool traverse(const SceneDev& S, Scratch& W, const Ray& world_ray, double
     V3 inv_d = v3(1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z);
     if (S.dir_res != 0u &&
         for_each_direction_candidate(S, world_ray, cx, [&](int node, const RtShape* __restrict__ sh, const Ray& r, int n) {
-            return process_leaf<SHADOW>(S, W, node, sh, sh->kind_flags, r, n, limit, best, cx);
+            return process_leaf(S, W, node, sh, sh->kind_flags, r, n, shadow, limit, best, cx);
         }))
         return true;
     for (;;) {
         int s = -1;
         if (bvh) {
-            if (cur >= 0) {
+            // box tests only, until this lane holds a leaf whose box the ray meets (or the level
+            // ends): lanes wait here for each other, so the expensive leaf code below runs with
+            // most of the wave active instead of once per lane per step
+            const double t_far = shadow ? limit : best.t;
+            while (cur >= 0) {
                 const RtBvhNode* __restrict__ nd = S.bvh + cur;
                 count(cx, ST_BVH_BOX);
-                const double t_far = SHADOW ? limit : best.t;
-                if (!accel_box(nd, ray.o, inv_d, t_far)) {
-                    cur = nd->miss;
-                    continue;
-                }
+                const int miss = nd->miss;
                 const int leaf = nd->shape;
-                if (leaf < 0) {
+                if (!accel_box(nd, ray.o, inv_d, t_far)) {
+                    cur = miss;
+                } else if (leaf < 0) {
                     ++cur;
-                    continue;
+                } else {
+                    s = leaf;
+                    cur = miss;
+                    break;
                 }
-                s = leaf;
-                cur = nd->miss;
             }
         } else if (cur < end) {
             s = cur;
@@ -552,30 +591,27 @@ RT_DEV bool traverse(const SceneDev& S, Scratch& W, const Ray& world_ray, double
         const unsigned kf = sh->kind_flags;
         const unsigned kind = RT_KIND(kf);
         if (kind != RT_GROUP) {
-            if (process_leaf<SHADOW>(S, W, s, sh, kf, ray, level, limit, best, cx)) return true;
+            if (process_leaf(S, W, s, sh, kf, ray, level, shadow, limit, best, cx)) return true;
             continue;
         }
-        {
-            const Ray lr = transform_ray(sh->inv, ray);
-            const RtGroup* __restrict__ g = S.groups + sh->param;
-            count(cx, ST_RAY_XFORM);
-            count(cx, ST_GATES);
-            if (g->n_children == 0u || !box_intersects(g->bmin, g->bmax, lr)) continue;  // compound.rs:93-95
-            W.rays[level] = ray;
-            W.cur[level] = cur;
-            W.end[level] = bvh ? -2 : end;
-            ++level;
-            ray = lr;
-            const int root = g->bvh_root;
-            bvh = root >= 0;
-            if (bvh) {
-                cur = root;
-                inv_d = v3(1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z);
-            } else {
-                cur = s + 1;
-                end = (int)sh->skip;
-            }
-            continue;
+        const Ray lr = transform_ray(sh->inv, ray);
+        const RtGroup* __restrict__ g = S.groups + sh->param;
+        count(cx, ST_RAY_XFORM);
+        count(cx, ST_GATES);
+        if (g->n_children == 0u || !box_intersects(g->bmin, g->bmax, lr)) continue;  // compound.rs:93-95
+        W.rays[level] = ray;
+        W.cur[level] = cur;
+        W.end[level] = bvh ? -2 : end;
+        ++level;
+        ray = lr;
+        const int root = g->bvh_root;
+        bvh = root >= 0;
+        if (bvh) {
+            cur = root;
+            inv_d = v3(1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z);
+        } else {
+            cur = s + 1;
+            end = (int)sh->skip;
         }
     }
     return false;
@@ -633,7 +669,7 @@ struct Comps {
 
 // The containers walk of prepare_computations (intersection.rs:50-75) on the full sorted list.
 template <bool STATS>
-RT_DEV void containers_pass(const SceneDev& S, Scratch& W, const Ray& world_ray, double hit_t, double& n1, double& n2,
+RT_DEV_COLD void containers_pass(const SceneDev& S, Scratch& W, const Ray& world_ray, double hit_t, double& n1, double& n2,
                             Ctx<STATS>& cx) {
     count(cx, ST_CONTAINER_PASSES);
     // the walk stops at the first entry ~equal to the hit; entries that far beyond it
@@ -728,7 +764,7 @@ RT_DEV bool is_shadowed(const SceneDev& S, Scratch& W, V3 point, V3 light_positi
         return false;
     }
     Best unused{0.0, -1};
-    return traverse<true>(S, W, r, distance, unused, cx);
+    return trace(S, W, r, true, distance, unused, cx);
 }
 
 // Primitive::lighting (primitive.rs:111-151); `color` is the material or pattern colour.
@@ -776,20 +812,46 @@ template <bool STATS>
 RT_DEV bool find_hit(const SceneDev& S, Scratch& W, const Ray& ray, Best& best, Ctx<STATS>& cx) {
     best.t = __builtin_inf();
     best.idx = -1;
-    traverse<false>(S, W, ray, 0.0, best, cx);
+    trace(S, W, ray, false, 0.0, best, cx);
     return best.idx >= 0;
 }
 
+// The hit being lit: what shade_hit keeps while its shadow feelers are traced.  (Kept in
+// registers on purpose: parking it in the private frame stack cost 20-30 % on small scenes.)
+struct Shade {
+    V3 over, under, eye, normal, reflect_v, color, surface;
+    double n1, n2;
+    int mat;
+    unsigned li;  // next light
+    int want_n;
+};
+
+// One loop iteration traces ONE ray per lane -- a colour ray (primary, reflected, refracted) or
+// a shadow feeler -- and then advances that lane's shade_hit state machine; the wave never
+// splits into "lanes tracing shadows" and "lanes tracing colour rays".
 template <bool STATS>
 RT_DEV V3 color_at(const SceneDev& S, Scratch& W, Frame* frames, Ray ray, int remaining, Ctx<STATS>& cx) {
     int sp = 0;
-    V3 value = v3(0.0, 0.0, 0.0);
+    bool shadow = false;
+    double limit = 0.0;
+    Shade sd;
+    sd.li = 0u;
+    sd.mat = 0;
+    sd.want_n = 0;
     for (;;) {
-        // ---- one World::color_at node, up to the point where it needs its children
         Best hit;
-        bool descend = false;
-        if (!find_hit(S, W, ray, hit, cx)) {
-            value = v3(0.0, 0.0, 0.0);
+        hit.t = __builtin_inf();
+        hit.idx = -1;
+        const bool occluded = trace(S, W, ray, shadow, limit, hit, cx);
+        bool have_value = false;
+        V3 value = v3(0.0, 0.0, 0.0);
+        if (shadow) {  // light sd.li is answered (world.rs:58-70)
+            const RtLight light = S.lights[sd.li];
+            const RtMaterial m = S.mats[sd.mat];
+            sd.surface = sd.surface + lighting(m, sd.color, light, sd.over, sd.eye, sd.normal, occluded, cx);
+            ++sd.li;
+        } else if (hit.idx < 0) {  // world.rs:41: a miss is BLACK
+            have_value = true;
         } else {
             const RtShape* __restrict__ sh = S.shapes + hit.idx;
             const RtMaterial m = S.mats[sh->material];
@@ -805,36 +867,60 @@ RT_DEV V3 color_at(const SceneDev& S, Scratch& W, Frame* frames, Ray ray, int re
                 color = pattern_eval(S.pats, m.pattern, c.object_over_point, nodes);
                 count(cx, ST_PATTERN_NODES, nodes);
             }
-            V3 surface = v3(0.0, 0.0, 0.0);
-            for (uint32_t li = 0; li < S.n_lights; ++li) {
-                const RtLight light = S.lights[li];
-                const bool shadowed =
-                    is_shadowed(S, W, c.over_point, v3(light.position[0], light.position[1], light.position[2]), cx);
-                surface = surface + lighting(m, color, light, c.over_point, c.eye_v, c.normal_v, shadowed, cx);
+            sd.over = c.over_point, sd.under = c.under_point, sd.eye = c.eye_v, sd.normal = c.normal_v;
+            sd.reflect_v = c.reflect_v, sd.color = color, sd.surface = v3(0.0, 0.0, 0.0);
+            sd.n1 = c.n1, sd.n2 = c.n2, sd.mat = (int)sh->material, sd.li = 0u, sd.want_n = want_n ? 1 : 0;
+        }
+        bool retrace = false;
+        if (!have_value) {
+            // remaining lights: one shadow feeler each
+            while (sd.li < S.n_lights) {
+                const RtLight light = S.lights[sd.li];
+                const V3 lp = v3(light.position[0], light.position[1], light.position[2]);
+                if (S.flags & RT_SCENE_HAS_SHADOWLESS) {  // needs the sorted set: see is_shadowed
+                    const bool in_shadow = is_shadowed(S, W, sd.over, lp, cx);
+                    const RtMaterial m = S.mats[sd.mat];
+                    sd.surface = sd.surface + lighting(m, sd.color, light, sd.over, sd.eye, sd.normal, in_shadow, cx);
+                    ++sd.li;
+                    continue;
+                }
+                const V3 v = lp - sd.over;  // world.rs:86-89
+                limit = magnitude(v);
+                ray = Ray{sd.over, normalize(v)};
+                shadow = true;
+                count(cx, ST_RAY_SHADOW);
+                retrace = true;
+                break;
             }
-            const bool do_reflect = !(m.reflective == 0.0 || remaining == 0);  // world.rs:99
+        }
+        if (retrace) continue;
+        if (!have_value) {  // all lights in: reflected_color / refracted_color (world.rs:72-82,98-127)
+            const RtMaterial m = S.mats[sd.mat];
+            const bool do_reflect = !(m.reflective == 0.0 || remaining == 0);
             bool do_refract = false;
             Ray refract_ray = ray;
-            if (want_n) {  // world.rs:109-127
-                const double n_ratio = c.n1 / c.n2;
-                const double cos_i = dot(c.eye_v, c.normal_v);
+            if (sd.want_n != 0) {
+                const double n_ratio = sd.n1 / sd.n2;
+                const double cos_i = dot(sd.eye, sd.normal);
                 const double sin2_t = (n_ratio * n_ratio) * (1.0 - cos_i * cos_i);
                 if (!(sin2_t > 1.0)) {
                     const double cos_t = sqrt(1.0 - sin2_t);
                     do_refract = true;
-                    refract_ray.o = c.under_point;
-                    refract_ray.d = c.normal_v * (n_ratio * cos_i - cos_t) - c.eye_v * n_ratio;
+                    refract_ray.o = sd.under;
+                    refract_ray.d = sd.normal * (n_ratio * cos_i - cos_t) - sd.eye * n_ratio;
                 }
             }
             const bool use_schlick = m.reflective > 0.0 && m.transparency > 0.0;
             double reflectance = 0.0;
             if (use_schlick && remaining != 0) {
                 count(cx, ST_SCHLICK);
+                Comps c;
+                c.eye_v = sd.eye, c.normal_v = sd.normal, c.n1 = sd.n1, c.n2 = sd.n2;
                 reflectance = schlick(c);
             }
             if (do_reflect || do_refract) {
                 Frame& f = frames[sp];
-                f.surface = surface;
+                f.surface = sd.surface;
                 f.reflected = v3(0.0, 0.0, 0.0);
                 f.refract_ray = refract_ray;
                 f.reflective = m.reflective;
@@ -844,19 +930,18 @@ RT_DEV V3 color_at(const SceneDev& S, Scratch& W, Frame* frames, Ray ray, int re
                 f.state = do_reflect ? (do_refract ? FR_REFLECT_THEN_REFRACT : FR_REFLECT_ONLY) : FR_REFRACT;
                 ++sp;
                 --remaining;
+                shadow = false;
                 if (do_reflect) {
                     count(cx, ST_RAY_REFLECT);
-                    ray = Ray{c.over_point, c.reflect_v};
+                    ray = Ray{sd.over, sd.reflect_v};
                 } else {
                     count(cx, ST_RAY_REFRACT);
                     ray = refract_ray;
                 }
-                descend = true;
-            } else {
-                value = combine(surface, v3(0.0, 0.0, 0.0), v3(0.0, 0.0, 0.0), use_schlick, reflectance);
+                continue;
             }
+            value = combine(sd.surface, v3(0.0, 0.0, 0.0), v3(0.0, 0.0, 0.0), use_schlick, reflectance);
         }
-        if (descend) continue;
         // ---- hand `value` to the waiting frames
         for (;;) {
             if (sp == 0) return value;
@@ -865,8 +950,8 @@ RT_DEV V3 color_at(const SceneDev& S, Scratch& W, Frame* frames, Ray ray, int re
                 f.reflected = value * f.reflective;
                 f.state = FR_REFRACT;
                 ray = f.refract_ray;
+                shadow = false;
                 count(cx, ST_RAY_REFRACT);
-                descend = true;
                 break;
             }
             V3 reflected, refracted;

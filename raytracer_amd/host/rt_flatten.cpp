@@ -253,6 +253,18 @@ struct Flattener {
         return idx;
     }
 
+    // A level is walked through an acceleration structure when it is large, or when it holds a
+    // compound: culling a whole group or CSG subtree (the reference gives CSG nodes no gate at
+    // all, compound.rs:106-116) pays even among a handful of siblings.  Small levels of plain
+    // primitives stay linear: every lane then walks the same sequence.
+    bool wants_bvh(size_t n, const std::vector<Shape>& children) const {
+        if (n >= opt.bvh_min_children) return true;
+        if (n < 2) return false;
+        for (const Shape& c : children)
+            if (!c.is_primitive()) return true;
+        return false;
+    }
+
     // Appends the subtree of `s`; returns its acceleration box in the parent's space.
     ABox emit(const Shape& s, int32_t parent, uint32_t depth) {
         const uint32_t idx = static_cast<uint32_t>(out.shapes.size());
@@ -321,7 +333,7 @@ struct Flattener {
                 items.push_back(BvhItem{emit(child, static_cast<int32_t>(idx), depth + 1), child_idx});
             }
             for (const BvhItem& it : items) inner.merge(it.box);
-            if (opt.build_bvh && csg_depth == 0 && items.size() >= opt.bvh_min_children)
+            if (opt.build_bvh && csg_depth == 0 && wants_bvh(items.size(), c.children()))
                 out.groups[group_slot].bvh_root = build_bvh(items, out.bvh_nodes);
         } else {
             rec.kind_flags |= static_cast<uint32_t>(c.operation()) << RT_FLAG_CSG_OP_SHIFT;
@@ -495,7 +507,7 @@ FlatScene flatten(const World& world, const FlattenOptions& opt) {
         const uint32_t idx = static_cast<uint32_t>(f.out.shapes.size());
         top.push_back(BvhItem{f.emit(s, -1, 0), idx});
     }
-    if (opt.build_bvh && top.size() >= opt.bvh_min_children) f.out.world_bvh_root = build_bvh(top, f.out.bvh_nodes);
+    if (opt.build_bvh && f.wants_bvh(top.size(), world.shapes())) f.out.world_bvh_root = build_bvh(top, f.out.bvh_nodes);
     if (opt.build_bvh && opt.dir_res > 0) build_direction_index(f.out, opt.dir_res);
     return std::move(f.out);
 }
