@@ -278,6 +278,11 @@ RT_DEV int f64_as_i32(double v) {
     return (int)v;
 }
 
+#ifdef RT_INLINE_PATTERN
+#define RT_PATTERN_FN __device__ __forceinline__
+#else
+#define RT_PATTERN_FN __device__ __noinline__
+#endif
 #define RT_PATTERN_STACK 8  // nesting depth of blend/gradient/radial-gradient nodes
 
 // Pattern::pattern_at (pattern.rs:87-91) with Kind::pattern_at / Mixture::* (pattern.rs:103-199)
@@ -285,7 +290,7 @@ RT_DEV int f64_as_i32(double v) {
 // tail calls; only the arithmetic mixtures need a frame.  The reference evaluates
 // both children of a selector and discards one; patterns are pure, so the value
 // is the same.
-__device__ __noinline__ V3 pattern_eval(const RtPattern* __restrict__ pats, int root, V3 object_point,
+RT_PATTERN_FN V3 pattern_eval(const RtPattern* __restrict__ pats, int root, V3 object_point,
                                         unsigned& nodes_evaluated) {
     int f_node[RT_PATTERN_STACK];
     V3 f_pp[RT_PATTERN_STACK];

@@ -19,6 +19,9 @@
 
 using namespace rtd;
 
+#ifndef RT_WAVES_PER_SIMD_FLAT
+#define RT_WAVES_PER_SIMD_FLAT 2
+#endif
 #ifndef RT_WAVES_PER_SIMD
 #define RT_WAVES_PER_SIMD 2  // register budget of the tracing kernels: 512 / this many VGPR+AGPR per lane
 #endif
@@ -30,8 +33,8 @@ struct RowMap {  // local row k -> image row (rt_hip_render_rows)
     uint32_t part, n_parts, band_rows, n_local_rows;
 };
 
-template <bool STATS>
-__device__ void flush_stats(Ctx<STATS>& cx, RtStats* __restrict__ stats, unsigned* __restrict__ status) {
+template <bool STATS, bool FLAT>
+__device__ void flush_stats(Ctx<STATS, FLAT>& cx, RtStats* __restrict__ stats, unsigned* __restrict__ status) {
     if (cx.status) atomicOr(status, cx.status);
     if constexpr (STATS) {
         unsigned long long* out = reinterpret_cast<unsigned long long*>(stats);
@@ -45,16 +48,17 @@ __device__ void flush_stats(Ctx<STATS>& cx, RtStats* __restrict__ stats, unsigne
     }
 }
 
-template <bool STATS>
-__global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const SceneDev* __restrict__ scene, RtCameraDesc cam, int depth, RowMap rows,
+// FLAT: the scene holds only primitives and no acceleration structure (RT_SCENE_FLAT); that
+// variant carries none of the group / CSG / BVH machinery and so needs far fewer registers.
+template <bool STATS, bool FLAT>
+__global__ __launch_bounds__(256, FLAT ? RT_WAVES_PER_SIMD_FLAT : RT_WAVES_PER_SIMD) void render_kernel(const SceneDev S, RtCameraDesc cam, int depth, RowMap rows,
                                                      double* __restrict__ out, RtStats* __restrict__ stats,
                                                      unsigned* __restrict__ status) {
-    const SceneDev& S = *scene;  // uniform pointer: table bases come through the scalar cache
     // 16x16 pixels per block, one 8x8 tile per wave: neighbouring pixels share a wave
     const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const unsigned x = blockIdx.x * 16u + (wave & 1u) * 8u + (lane & 7u);
     const unsigned k = blockIdx.y * 16u + (wave >> 1) * 8u + (lane >> 3);
-    Ctx<STATS> cx;
+    Ctx<STATS, FLAT> cx;
     cx.status = 0;
     if constexpr (STATS) {
 #pragma unroll
@@ -80,12 +84,12 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Sc
     flush_stats(cx, stats, status);
 }
 
-__global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void color_at_kernel(const SceneDev* __restrict__ scene,
-                                                       const double* __restrict__ rays, unsigned n, int depth,
-                                                       double* __restrict__ out, unsigned* __restrict__ status) {
-    const SceneDev& S = *scene;
+template <bool FLAT>
+__global__ __launch_bounds__(256, FLAT ? RT_WAVES_PER_SIMD_FLAT : RT_WAVES_PER_SIMD) void color_at_kernel(const SceneDev S, const double* __restrict__ rays,
+                                                       unsigned n, int depth, double* __restrict__ out,
+                                                       unsigned* __restrict__ status) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-    Ctx<false> cx;
+    Ctx<false, FLAT> cx;
     cx.status = 0;
     if (i < n) {
         Scratch W;
@@ -100,12 +104,11 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void color_at_kernel(const 
     flush_stats(cx, nullptr, status);
 }
 
-__global__ __launch_bounds__(256) void probe_kernel(const SceneDev* __restrict__ scene, const double* __restrict__ rays,
-                                                    unsigned n, double* __restrict__ out,
-                                                    unsigned* __restrict__ status) {
-    const SceneDev& S = *scene;
+template <bool FLAT>
+__global__ __launch_bounds__(256) void probe_kernel(const SceneDev S, const double* __restrict__ rays, unsigned n,
+                                                    double* __restrict__ out, unsigned* __restrict__ status) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-    Ctx<false> cx;
+    Ctx<false, FLAT> cx;
     cx.status = 0;
     if (i < n) {
         Scratch W;
@@ -356,12 +359,15 @@ int launch_render(const RtScene* scene, const RtCameraDesc* cam, uint32_t depth,
     const dim3 block(256);
     const dim3 grid((cam->hsize + 15u) / 16u, (rows.n_local_rows + 15u) / 16u);
     if (grid.y > 65535u * 16u) return RT_ERR_INVALID_ARG;
-    if (d_stats)
-        hipLaunchKernelGGL(render_kernel<true>, grid, block, 0, stream, scene->d_dev, *cam, (int)depth, rows, d_out, d_stats,
+    const bool flat = (scene->dev.flags & RT_SCENE_FLAT) != 0;
+    auto go = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, grid, block, 0, stream, scene->dev, *cam, (int)depth, rows, d_out, d_stats,
                            scene->d_status);
+    };
+    if (d_stats)
+        flat ? go(render_kernel<true, true>) : go(render_kernel<true, false>);
     else
-        hipLaunchKernelGGL(render_kernel<false>, grid, block, 0, stream, scene->d_dev, *cam, (int)depth, rows, d_out,
-                           (RtStats*)nullptr, scene->d_status);
+        flat ? go(render_kernel<false, true>) : go(render_kernel<false, false>);
     HIP_TRY(hipGetLastError());
     return RT_OK;
 }
@@ -568,8 +574,12 @@ int rt_hip_color_at(const RtScene* scene, const double* rays, uint32_t n, uint32
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_rays), (size_t)n * 6u * sizeof(double)));
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_out), (size_t)n * 3u * sizeof(double)));
         HIP_TRY(hipMemcpy(d_rays, rays, (size_t)n * 6u * sizeof(double), hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(color_at_kernel, dim3((n + 255u) / 256u), dim3(256), 0, nullptr, scene->d_dev, d_rays, n,
-                           (int)depth, d_out, scene->d_status);
+        if (scene->dev.flags & RT_SCENE_FLAT)
+            hipLaunchKernelGGL(color_at_kernel<true>, dim3((n + 255u) / 256u), dim3(256), 0, nullptr, scene->dev, d_rays,
+                               n, (int)depth, d_out, scene->d_status);
+        else
+            hipLaunchKernelGGL(color_at_kernel<false>, dim3((n + 255u) / 256u), dim3(256), 0, nullptr, scene->dev, d_rays,
+                               n, (int)depth, d_out, scene->d_status);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpy(out_rgb, d_out, (size_t)n * 3u * sizeof(double), hipMemcpyDeviceToHost));
         return read_status(scene, nullptr);
@@ -588,8 +598,12 @@ int rt_hip_probe(const RtScene* scene, const double* rays, uint32_t n, double* o
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_rays), (size_t)n * 6u * sizeof(double)));
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_out), (size_t)n * 16u * sizeof(double)));
         HIP_TRY(hipMemcpy(d_rays, rays, (size_t)n * 6u * sizeof(double), hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(probe_kernel, dim3((n + 255u) / 256u), dim3(256), 0, nullptr, scene->d_dev, d_rays, n, d_out,
-                           scene->d_status);
+        if (scene->dev.flags & RT_SCENE_FLAT)
+            hipLaunchKernelGGL(probe_kernel<true>, dim3((n + 255u) / 256u), dim3(256), 0, nullptr, scene->dev, d_rays, n,
+                               d_out, scene->d_status);
+        else
+            hipLaunchKernelGGL(probe_kernel<false>, dim3((n + 255u) / 256u), dim3(256), 0, nullptr, scene->dev, d_rays, n,
+                               d_out, scene->d_status);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpy(out, d_out, (size_t)n * 16u * sizeof(double), hipMemcpyDeviceToHost));
         return read_status(scene, nullptr);

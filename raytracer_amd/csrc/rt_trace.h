@@ -69,13 +69,13 @@ enum {
 #define RT_STATUS_LIST_OVERFLOW (1u << 6)  // 1 << -RT_ERR_LIST_OVERFLOW
 #define RT_STATUS_NAN_T (1u << 7)          // 1 << -RT_ERR_NAN_T
 
-template <bool STATS>
+template <bool STATS, bool FLAT>
 struct Ctx {
     unsigned cnt[STATS ? ST_COUNT : 1];
     unsigned status;
 };
-template <bool STATS>
-RT_DEV void count(Ctx<STATS>& cx, int what, unsigned n = 1) {
+template <bool STATS, bool FLAT>
+RT_DEV void count(Ctx<STATS, FLAT>& cx, int what, unsigned n = 1) {
     if constexpr (STATS) cx.cnt[what] += n;
 }
 
@@ -135,9 +135,55 @@ RT_DEV void finish_hits(PrimHits& h, unsigned& status) {
     h.keep = keep;
 }
 
-template <bool STATS>
+// Wave-uniform read of a table record through the constant address space: one scalar load
+// per wave, the record then sits in SGPRs.  Only for addresses every lane agrees on; the
+// tables are read-only for the lifetime of a launch.
+template <class T>
+RT_DEV T load_uniform(const T* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(sizeof(T) % 8 == 0, "records are whole quadwords");
+    typedef const __attribute__((address_space(4))) unsigned long long* ConstQwords;
+    ConstQwords q = (ConstQwords)(p);
+    T out;
+    unsigned long long* o = reinterpret_cast<unsigned long long*>(&out);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 8; ++i) o[i] = q[i];
+    return out;
+#else
+    return *p;
+#endif
+}
+
+template <bool STATS, bool FLAT>
+RT_DEV void prim_intersect_rec(const double* __restrict__ inv, unsigned kf, const RtConic* __restrict__ conic,
+                               const RtTriangle* __restrict__ tri, const Ray& parent_ray, PrimHits& h,
+                               Ctx<STATS, FLAT>& cx) {
+    const Ray r = transform_ray(inv, parent_ray);  // shape.rs:28-32
+    const unsigned kind = RT_KIND(kf);
+    count(cx, ST_RAY_XFORM);
+    count(cx, ST_PRIM0 + (int)kind);
+    h.n = 0;
+    if (kind == RT_SPHERE) {
+        h.n = sphere_intersect(r, h.t);
+    } else if (kind == RT_PLANE) {
+        h.n = plane_intersect(r, h.t);
+    } else if (kind == RT_CUBE) {
+        h.n = cube_intersect(r, h.t);
+    } else if (kind == RT_CYLINDER || kind == RT_CONE) {
+        const RtConic c = *conic;
+        const bool closed = (kf & RT_FLAG_CLOSED) != 0;
+        h.n = kind == RT_CYLINDER ? cylinder_intersect(r, c.minimum, c.maximum, closed, h.t)
+                                  : cone_intersect(r, c.minimum, c.maximum, closed, h.t);
+    } else {
+        double u, v;
+        h.n = triangle_intersect(tri, r, h.t, u, v);
+    }
+    finish_hits(h, cx.status);
+}
+
+template <bool STATS, bool FLAT>
 RT_DEV void prim_intersect(const SceneDev& S, const RtShape* __restrict__ sh, unsigned kf, const Ray& parent_ray,
-                           PrimHits& h, Ctx<STATS>& cx) {
+                           PrimHits& h, Ctx<STATS, FLAT>& cx) {
     const Ray r = transform_ray(sh->inv, parent_ray);  // shape.rs:28-32
     const unsigned kind = RT_KIND(kf);
     count(cx, ST_RAY_XFORM);
@@ -251,9 +297,9 @@ RT_DEV bool accel_line_box(const RtBvhNode* __restrict__ nd, const V3& o, const 
 // through it (groups inside CSG nodes never carry one: see the flattener).
 // Shape::intersect / Compound::local_intersect / World::intersections
 // (shape.rs:28-32, compound.rs:87-117, world.rs:45-53).
-template <bool USE_BVH, bool STATS>
+template <bool USE_BVH, bool STATS, bool FLAT>
 RT_DEV int list_eval_core(const SceneDev& S, Scratch& W, int begin, int end, int level0, int base0, int top0,
-                          double bound, Ctx<STATS>& cx) {
+                          double bound, Ctx<STATS, FLAT>& cx) {
     int level = level0;
     int top = top0;
     int base = base0;  // start of the list entries currently go to
@@ -348,9 +394,9 @@ RT_DEV int list_eval_core(const SceneDev& S, Scratch& W, int begin, int end, int
 }
 
 // A compound subtree evaluated on its own (CSG nodes met by the streaming traversal).
-template <bool STATS>
+template <bool STATS, bool FLAT>
 RT_DEV_COLD int list_eval(const SceneDev& S, Scratch& W, int begin, int end, int level0, int base0, double bound,
-                     Ctx<STATS>& cx) {
+                     Ctx<STATS, FLAT>& cx) {
     return list_eval_core<false>(S, W, begin, end, level0, base0, base0, bound, cx);
 }
 
@@ -388,9 +434,9 @@ RT_DEV int ancestor_chain(const SceneDev& S, int parent, int* chain) {  // inner
 // a primitive is intersected, a CSG node is materialised through list_eval; the surviving hits go
 // to the closest-hit reduction or, for a shadow feeler, to the "anything before the light" test.
 // Returns true when a shadow hit was found.
-template <bool STATS>
+template <bool STATS, bool FLAT>
 RT_DEV bool process_leaf(const SceneDev& S, Scratch& W, int s, const RtShape* __restrict__ sh, unsigned kf,
-                         const Ray& ray, int level, bool shadow, double limit, Best& best, Ctx<STATS>& cx) {
+                         const Ray& ray, int level, bool shadow, double limit, Best& best, Ctx<STATS, FLAT>& cx) {
     if (RT_KIND(kf) <= RT_SMOOTH_TRIANGLE) {
         if (shadow && !(kf & RT_FLAG_HAS_SHADOW)) return false;
         PrimHits h;
@@ -427,8 +473,8 @@ RT_DEV bool process_leaf(const SceneDev& S, Scratch& W, int s, const RtShape* __
 // level) for each such conic (or its outermost CSG ancestor) that the reference's own group
 // gates let the ray reach; f returns true to stop.  A shape evaluated here and met again by the
 // box walk contributes the same hits twice, which changes nothing.
-template <bool STATS, class F>
-RT_DEV bool for_each_direction_candidate(const SceneDev& S, const Ray& ray, Ctx<STATS>& cx, F&& f) {
+template <bool STATS, bool FLAT, class F>
+RT_DEV bool for_each_direction_candidate(const SceneDev& S, const Ray& ray, Ctx<STATS, FLAT>& cx, F&& f) {
     const V3 d = ray.d;
     const double len2 = dot(d, d);
     // the cells are built for unit directions; a shorter direction widens the region
@@ -484,9 +530,31 @@ RT_DEV bool for_each_direction_candidate(const SceneDev& S, const Ray& ray, Ctx<
 }
 
 // World::intersections (world.rs:45-53) as a sorted list at W.lt/lid[0, n), cut at t <= bound.
-template <bool STATS>
-RT_DEV_COLD int world_list(const SceneDev& S, Scratch& W, const Ray& ray, double bound, Ctx<STATS>& cx) {
+template <bool STATS, bool FLAT>
+RT_DEV_COLD int world_list(const SceneDev& S, Scratch& W, const Ray& ray, double bound, Ctx<STATS, FLAT>& cx) {
     int top = 0;
+    if constexpr (FLAT) {
+        const int n = (int)S.n_shapes;
+        for (int s = 0; s < n; ++s) {
+            const RtShape rec = load_uniform(S.shapes + s);
+            const unsigned kf = rec.kind_flags;
+            const unsigned kind = RT_KIND(kf);
+            RtConic conic{0.0, 0.0};
+            if (kind == RT_CYLINDER || kind == RT_CONE) conic = load_uniform(S.conics + rec.param);
+            RtTriangle tri;
+            if (kind == RT_TRIANGLE || kind == RT_SMOOTH_TRIANGLE) tri = load_uniform(S.tris + rec.param);
+            PrimHits h;
+            prim_intersect_rec(rec.inv, kf, &conic, &tri, ray, h, cx);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (((h.keep >> k) & 1u) && h.t[k] <= bound) {
+                    top = list_insert(W, 0, top, h.t[k], (uint32_t)s, cx.status);
+                    count(cx, ST_LIST_ENTRIES);
+                }
+            }
+        }
+        return top;
+    } else {
     if (S.dir_res != 0u) {
         for_each_direction_candidate(S, ray, cx, [&](int node, const RtShape* __restrict__ sh, const Ray& r, int n) {
             const unsigned kf = sh->kind_flags;
@@ -507,26 +575,32 @@ RT_DEV_COLD int world_list(const SceneDev& S, Scratch& W, const Ray& ray, double
     }
     W.rays[0] = ray;
     return list_eval_core<true>(S, W, 0, (int)S.n_shapes, 0, 0, top, bound, cx);
+    }
 }
 
 // One ray against the world.  shadow == false: closest hit into `best` (world.rs:32-36,
 // intersection.rs:154-158).  shadow == true: returns true as soon as a shadow-casting
 // primitive is met at 0 <= t < limit (world.rs:85-96).  Colour rays and shadow feelers share
 // this one loop so that the lanes of a wave stay together whatever each one is tracing.
-template <bool STATS>
+template <bool STATS, bool FLAT>
 RT_DEV bool trace(const SceneDev& S, Scratch& W, const Ray& world_ray, bool shadow, double limit, Best& best,
-                  Ctx<STATS>& cx) {
-    if (S.flags & RT_SCENE_FLAT) {
+                  Ctx<STATS, FLAT>& cx) {
+    if constexpr (FLAT) {
         // only primitives, no acceleration structure: every lane walks the same shape sequence,
         // so the records are fetched once per wave through the scalar cache
         bool found = false;
         const int n = (int)S.n_shapes;
         for (int s = 0; s < n; ++s) {
-            const RtShape* __restrict__ sh = S.shapes + s;
-            const unsigned kf = sh->kind_flags;
+            const RtShape rec = load_uniform(S.shapes + s);
+            const unsigned kf = rec.kind_flags;
+            const unsigned kind = RT_KIND(kf);
+            RtConic conic{0.0, 0.0};
+            if (kind == RT_CYLINDER || kind == RT_CONE) conic = load_uniform(S.conics + rec.param);
+            RtTriangle tri;
+            if (kind == RT_TRIANGLE || kind == RT_SMOOTH_TRIANGLE) tri = load_uniform(S.tris + rec.param);
             if (shadow && !(kf & RT_FLAG_HAS_SHADOW)) continue;
             PrimHits h;
-            prim_intersect(S, sh, kf, world_ray, h, cx);
+            prim_intersect_rec(rec.inv, kf, &conic, &tri, world_ray, h, cx);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if ((h.keep >> k) & 1u) {
@@ -539,7 +613,7 @@ RT_DEV bool trace(const SceneDev& S, Scratch& W, const Ray& world_ray, bool shad
             if (__builtin_amdgcn_ballot_w64(!found) == 0ull) break;  // every live lane is already in shadow
         }
         return found;
-    }
+    } else {
     int level = 0;
     Ray ray = world_ray;
     bool bvh = S.world_bvh_root >= 0;
@@ -615,6 +689,7 @@ RT_DEV bool trace(const SceneDev& S, Scratch& W, const Ray& world_ray, bool shad
         }
     }
     return false;
+    }
 }
 
 // ---- object space / normals (primitive.rs:153-192) -----------------------------------
@@ -668,9 +743,9 @@ struct Comps {
 };
 
 // The containers walk of prepare_computations (intersection.rs:50-75) on the full sorted list.
-template <bool STATS>
+template <bool STATS, bool FLAT>
 RT_DEV_COLD void containers_pass(const SceneDev& S, Scratch& W, const Ray& world_ray, double hit_t, double& n1, double& n2,
-                            Ctx<STATS>& cx) {
+                            Ctx<STATS, FLAT>& cx) {
     count(cx, ST_CONTAINER_PASSES);
     // the walk stops at the first entry ~equal to the hit; entries that far beyond it
     // cannot influence anything before it (dedupe windows are 1e-5 per nesting level)
@@ -702,14 +777,14 @@ RT_DEV_COLD void containers_pass(const SceneDev& S, Scratch& W, const Ray& world
     }
 }
 
-template <bool STATS>
+template <bool STATS, bool FLAT>
 RT_DEV void prepare_computations(const SceneDev& S, Scratch& W, const Ray& ray, const Best& hit, bool want_n1n2,
-                                 Comps& c, Ctx<STATS>& cx) {
+                                 Comps& c, Ctx<STATS, FLAT>& cx) {
     count(cx, ST_HITS_SHADED);
     const RtShape* __restrict__ sh = S.shapes + hit.idx;
     const unsigned kind = RT_KIND(sh->kind_flags);
     int chain[RT_STACK];
-    const int n = ancestor_chain(S, sh->parent, chain);
+    const int n = FLAT ? 0 : ancestor_chain(S, sh->parent, chain);
     count(cx, ST_NORMAL_LEVELS, 2u * (unsigned)(n + 1));
     const V3 point = ray.o + ray.d * hit.t;  // ray.rs:15-17
     c.idx = hit.idx;
@@ -746,8 +821,8 @@ RT_DEV double schlick(const Comps& c) {  // intersection.rs:182-200
 }
 
 // World::is_shadowed (world.rs:85-96)
-template <bool STATS>
-RT_DEV bool is_shadowed(const SceneDev& S, Scratch& W, V3 point, V3 light_position, Ctx<STATS>& cx) {
+template <bool STATS, bool FLAT>
+RT_DEV bool is_shadowed(const SceneDev& S, Scratch& W, V3 point, V3 light_position, Ctx<STATS, FLAT>& cx) {
     const V3 v = light_position - point;
     const double distance = magnitude(v);
     const Ray r{point, normalize(v)};
@@ -768,9 +843,9 @@ RT_DEV bool is_shadowed(const SceneDev& S, Scratch& W, V3 point, V3 light_positi
 }
 
 // Primitive::lighting (primitive.rs:111-151); `color` is the material or pattern colour.
-template <bool STATS>
+template <bool STATS, bool FLAT>
 RT_DEV V3 lighting(const RtMaterial& m, V3 color, const RtLight& light, V3 position, V3 eye_v, V3 normal_v,
-                   bool in_shadow, Ctx<STATS>& cx) {
+                   bool in_shadow, Ctx<STATS, FLAT>& cx) {
     count(cx, ST_LIGHTINGS);
     const V3 intensity = v3(light.intensity[0], light.intensity[1], light.intensity[2]);
     const V3 effective_color = hadamard(color, intensity);
@@ -808,8 +883,8 @@ RT_DEV V3 combine(V3 surface, V3 reflected, V3 refracted, bool use_schlick, doub
     return (surface + reflected) + refracted;
 }
 
-template <bool STATS>
-RT_DEV bool find_hit(const SceneDev& S, Scratch& W, const Ray& ray, Best& best, Ctx<STATS>& cx) {
+template <bool STATS, bool FLAT>
+RT_DEV bool find_hit(const SceneDev& S, Scratch& W, const Ray& ray, Best& best, Ctx<STATS, FLAT>& cx) {
     best.t = __builtin_inf();
     best.idx = -1;
     trace(S, W, ray, false, 0.0, best, cx);
@@ -829,8 +904,8 @@ struct Shade {
 // One loop iteration traces ONE ray per lane -- a colour ray (primary, reflected, refracted) or
 // a shadow feeler -- and then advances that lane's shade_hit state machine; the wave never
 // splits into "lanes tracing shadows" and "lanes tracing colour rays".
-template <bool STATS>
-RT_DEV V3 color_at(const SceneDev& S, Scratch& W, Frame* frames, Ray ray, int remaining, Ctx<STATS>& cx) {
+template <bool STATS, bool FLAT>
+RT_DEV V3 color_at(const SceneDev& S, Scratch& W, Frame* frames, Ray ray, int remaining, Ctx<STATS, FLAT>& cx) {
     int sp = 0;
     bool shadow = false;
     double limit = 0.0;
