@@ -74,6 +74,8 @@ def main():
         world, cam = rt.exercise(args.workload, W, H)
     flat = world.flatten(build_bvh=True)
     scene = rt.DeviceScene(flat)
+    fd = flat.desc.contents
+    scene_is_flat = fd.world_bvh_root < 0 and all((fd.shapes[i].kind_flags & 0xff) <= 6 for i in range(fd.n_shapes))
     cd = cam.desc()
     band = tiling.DEFAULT_BAND_ROWS
     n_parts = world_size
@@ -169,7 +171,7 @@ def main():
             },
             "roofline": {
                 "bound": "valu_f64",
-                "kernel": "render_kernel<false>",
+                "kernel": "render_kernel<STATS=false, FLAT=%s>" % ("true" if scene_is_flat else "false"),
                 "achieved": round(achieved, 4),
                 "peak": flops.PEAK_FP64_VALU_TFLOPS,
                 "unit": "TFLOP/s",
@@ -178,7 +180,7 @@ def main():
                 "frac_no_fma": round(achieved / flops.PEAK_FP64_VALU_NO_FMA_TFLOPS, 5),
                 "flops_per_launch": int(my_flops),
                 "kernel_ms": round(kernel_ms, 4),
-                "traffic": None,
+                "traffic": measured_traffic(args, n_parts),
             },
         }
         if n_parts == 1 and not args.no_cpu_baseline:
@@ -187,6 +189,16 @@ def main():
     if n_parts > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def measured_traffic(args, n_parts):
+    """HBM bytes per launch from the committed PMC passes of this same command (profiles/traffic.json;
+    counters cannot be read from inside the process), or None when this configuration was not profiled."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            return json.load(f).get(f"{args.workload}:{args.width}x{args.height}:{n_parts}")
+    except OSError:
+        return None
 
 
 def cpu_baseline(world, cam, args):
