@@ -82,7 +82,9 @@ def main():
     slots = tiling.padded_local_rows(H, n_parts, band)      # uniform shard height (gather needs equal sizes)
     my_rows = tiling.n_local_rows(H, rank, n_parts, band)
     shard = torch.zeros((slots, W, 3), dtype=torch.float64, device=dev)
-    gathered = [torch.empty_like(shard) for _ in range(n_parts)] if (rank == 0 and n_parts > 1) else None
+    # the root receives every shard into one buffer (no concatenation copy), then permutes rows into the frame
+    gathered_all = torch.empty((n_parts * slots, W, 3), dtype=torch.float64, device=dev) if (rank == 0 and n_parts > 1) else None
+    gathered = [gathered_all[i * slots:(i + 1) * slots] for i in range(n_parts)] if gathered_all is not None else None
     perm = torch.as_tensor(tiling.gather_permutation(H, n_parts, band), device=dev) if rank == 0 else None
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -94,7 +96,7 @@ def main():
         if n_parts > 1:
             dist.gather(shard, gathered, dst=0)
             if rank == 0:
-                return torch.cat(gathered, dim=0).index_select(0, perm)
+                return gathered_all.index_select(0, perm)
         return shard
 
     # ---- untimed counting launch: rays and the FLOP budget of this rank's share
@@ -131,7 +133,7 @@ def main():
         if n_parts > 1:
             dist.gather(shard, gathered, dst=0)
             if rank == 0:
-                frame = torch.cat(gathered, dim=0).index_select(0, perm)
+                frame = gathered_all.index_select(0, perm)
     torch.cuda.synchronize()
     if n_parts > 1:
         dist.barrier()

@@ -19,6 +19,9 @@
 
 using namespace rtd;
 
+#ifndef RT_STAGE_MAX_BYTES
+#define RT_STAGE_MAX_BYTES 32768u  // LDS image of a small scene's tables (160 KB of LDS per CU, 2 blocks resident)
+#endif
 #ifndef RT_WAVES_PER_SIMD_FLAT
 #define RT_WAVES_PER_SIMD_FLAT 2
 #endif
@@ -50,10 +53,28 @@ __device__ void flush_stats(Ctx<STATS, FLAT>& cx, RtStats* __restrict__ stats, u
 
 // FLAT: the scene holds only primitives and no acceleration structure (RT_SCENE_FLAT); that
 // variant carries none of the group / CSG / BVH machinery and so needs far fewer registers.
-template <bool STATS, bool FLAT>
-__global__ __launch_bounds__(256, FLAT ? RT_WAVES_PER_SIMD_FLAT : RT_WAVES_PER_SIMD) void render_kernel(const SceneDev S, RtCameraDesc cam, int depth, RowMap rows,
+//
+// STAGED (FLAT scenes whose tables fit RT_STAGE_MAX_BYTES): the block first copies the packed
+// table image into LDS and shades out of that copy; the per-lane, dependent record reads of
+// prepare_computations / lighting / pattern evaluation then cost an LDS access, not an L2 one.
+extern __shared__ __align__(16) unsigned char rt_lds[];
+
+template <bool STATS, bool FLAT, bool STAGED>
+__global__ __launch_bounds__(256, FLAT ? RT_WAVES_PER_SIMD_FLAT : RT_WAVES_PER_SIMD) void render_kernel(const SceneDev S_in, RtCameraDesc cam, int depth, RowMap rows,
                                                      double* __restrict__ out, RtStats* __restrict__ stats,
                                                      unsigned* __restrict__ status) {
+    SceneDev S = S_in;
+    if constexpr (STAGED) {
+        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(S_in.stage);
+        uint4* dst = reinterpret_cast<uint4*>(rt_lds);
+        for (unsigned i = threadIdx.x; i < S_in.stage_bytes / 16u; i += blockDim.x) dst[i] = src[i];
+        __syncthreads();
+        S.shapes = reinterpret_cast<const RtShape*>(rt_lds + S_in.stage_off[0]);
+        S.conics = reinterpret_cast<const RtConic*>(rt_lds + S_in.stage_off[1]);
+        S.mats = reinterpret_cast<const RtMaterial*>(rt_lds + S_in.stage_off[2]);
+        S.pats = reinterpret_cast<const RtPattern*>(rt_lds + S_in.stage_off[3]);
+        S.lights = reinterpret_cast<const RtLight*>(rt_lds + S_in.stage_off[4]);
+    }
     // 16x16 pixels per block, one 8x8 tile per wave: neighbouring pixels share a wave
     const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const unsigned x = blockIdx.x * 16u + (wave & 1u) * 8u + (lane & 7u);
@@ -360,14 +381,17 @@ int launch_render(const RtScene* scene, const RtCameraDesc* cam, uint32_t depth,
     const dim3 grid((cam->hsize + 15u) / 16u, (rows.n_local_rows + 15u) / 16u);
     if (grid.y > 65535u * 16u) return RT_ERR_INVALID_ARG;
     const bool flat = (scene->dev.flags & RT_SCENE_FLAT) != 0;
+    const bool staged = flat && scene->dev.stage_bytes != 0;
     auto go = [&](auto kernel) {
-        hipLaunchKernelGGL(kernel, grid, block, 0, stream, scene->dev, *cam, (int)depth, rows, d_out, d_stats,
-                           scene->d_status);
+        hipLaunchKernelGGL(kernel, grid, block, staged ? scene->dev.stage_bytes : 0u, stream, scene->dev, *cam, (int)depth,
+                           rows, d_out, d_stats, scene->d_status);
     };
     if (d_stats)
-        flat ? go(render_kernel<true, true>) : go(render_kernel<true, false>);
+        staged ? go(render_kernel<true, true, true>)
+               : (flat ? go(render_kernel<true, true, false>) : go(render_kernel<true, false, false>));
     else
-        flat ? go(render_kernel<false, true>) : go(render_kernel<false, false>);
+        staged ? go(render_kernel<false, true, true>)
+               : (flat ? go(render_kernel<false, true, false>) : go(render_kernel<false, false, false>));
     HIP_TRY(hipGetLastError());
     return RT_OK;
 }
@@ -481,6 +505,30 @@ int rt_hip_scene_create(const RtSceneDesc* desc, RtScene** out) {
     s->dev.n_lights = desc->n_lights;
     s->dev.world_bvh_root = desc->world_bvh_root;
     s->dev.flags = flags;
+    s->dev.g_shapes = shapes, s->dev.g_conics = conics, s->dev.g_tris = tris;
+    s->dev.stage = nullptr;
+    s->dev.stage_bytes = 0;
+    if (flags & RT_SCENE_FLAT) {  // pack the tables lanes index individually; small scenes shade out of LDS
+        std::vector<unsigned char> image;
+        auto put = [&](const void* src, size_t bytes, uint32_t* off) {
+            *off = (uint32_t)image.size();
+            const unsigned char* b = static_cast<const unsigned char*>(src);
+            image.insert(image.end(), b, b + bytes);
+            while (image.size() % 16u) image.push_back(0);
+        };
+        put(desc->shapes, sizeof(RtShape) * desc->n_shapes, &s->dev.stage_off[0]);
+        put(desc->conics, sizeof(RtConic) * desc->n_conics, &s->dev.stage_off[1]);
+        put(desc->materials, sizeof(RtMaterial) * desc->n_materials, &s->dev.stage_off[2]);
+        put(desc->patterns, sizeof(RtPattern) * desc->n_patterns, &s->dev.stage_off[3]);
+        put(desc->lights, sizeof(RtLight) * desc->n_lights, &s->dev.stage_off[4]);
+        if (!image.empty() && image.size() <= RT_STAGE_MAX_BYTES) {
+            unsigned char* d_image = nullptr;
+            rc = upload(image.data(), image.size(), &d_image);
+            if (d_image) s->allocations.push_back(d_image);
+            s->dev.stage = d_image;
+            s->dev.stage_bytes = rc == RT_OK ? (uint32_t)image.size() : 0u;
+        }
+    }
     {
         const hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->d_dev), sizeof(SceneDev));
         if (e != hipSuccess) {

@@ -57,6 +57,16 @@ struct SceneDev {
     uint32_t n_shapes, n_lights;
     int32_t world_bvh_root;
     uint32_t flags;
+    // wave-uniform walks read records through the scalar cache: always the copies in global memory
+    const RtShape* __restrict__ g_shapes;
+    const RtConic* __restrict__ g_conics;
+    const RtTriangle* __restrict__ g_tris;
+    // LDS staging of small scenes: one packed image of shapes | conics | materials | patterns | lights
+    // (the tables lanes index individually while shading); a workgroup copies it in at start and
+    // repoints the five table pointers above at its LDS copy.
+    const unsigned char* __restrict__ stage;
+    uint32_t stage_bytes;
+    uint32_t stage_off[5];
 };
 
 // ---- event counters (RtStats order) ------------------------------------------
@@ -286,6 +296,82 @@ RT_DEV bool accel_line_box(const RtBvhNode* __restrict__ nd, const V3& o, const 
     return !(t0 > t1) && !(t0 > bound);
 }
 
+RT_DEV int ancestor_chain(const SceneDev& S, int parent, int* chain) {  // innermost first == the trail
+    int n = 0;
+    for (int p = parent; p >= 0 && n < RT_STACK; p = S.shapes[p].parent) chain[n++] = p;
+    return n;
+}
+
+// Direction index (RtDirCand): conics whose "ray parallel to the surface" branch
+// (primitive.rs:486-490, no y-range check) fires for this ray direction must be evaluated
+// whatever the acceleration boxes say.  The iterator yields each such conic (or its outermost
+// CSG ancestor) that the reference's own group gates let the ray reach, with the ray in the
+// space of the node's parent and the node's nesting level.  A shape evaluated this way and met
+// again by the box walk contributes the same hits twice, which changes nothing.
+struct CandIter {
+    uint32_t k, e;
+    bool scan_all;
+};
+RT_DEV void cand_begin(const SceneDev& S, const Ray& ray, CandIter& it) {
+    const V3 d = ray.d;
+    const double len2 = dot(d, d);
+    // the cells are built for unit directions; a shorter direction widens the region
+    it.scan_all = !(len2 >= 0.999999);
+    it.k = 0;
+    it.e = S.n_dir_cands;
+    if (!it.scan_all) {
+        const double ax = fabs(d.x), ay = fabs(d.y), az = fabs(d.z);
+        int face;
+        double m, u, v;
+        if (ax >= ay && ax >= az) {
+            face = d.x >= 0.0 ? 0 : 1, m = ax, u = d.y, v = d.z;
+        } else if (ay >= az) {
+            face = d.y >= 0.0 ? 2 : 3, m = ay, u = d.x, v = d.z;
+        } else {
+            face = d.z >= 0.0 ? 4 : 5, m = az, u = d.x, v = d.y;
+        }
+        const double R = (double)S.dir_res;
+        int i = (int)((u / m + 1.0) * 0.5 * R);
+        int j = (int)((v / m + 1.0) * 0.5 * R);
+        const int hi = (int)S.dir_res - 1;
+        i = i < 0 ? 0 : (i > hi ? hi : i);
+        j = j < 0 ? 0 : (j > hi ? hi : j);
+        const uint32_t cell = ((uint32_t)face * S.dir_res + (uint32_t)j) * S.dir_res + (uint32_t)i;
+        it.k = S.dir_cell_start[cell];
+        it.e = S.dir_cell_start[cell + 1];
+    }
+}
+// Next reachable candidate: its shape index (or -1 when exhausted), `r` = ray at its level `n`.
+template <bool STATS, bool FLAT>
+RT_DEV int cand_next(const SceneDev& S, const Ray& ray, CandIter& it, Ray& r, int& n, Ctx<STATS, FLAT>& cx) {
+    const V3 d = ray.d;
+    while (it.k < it.e) {
+        const RtDirCand* __restrict__ c = S.dir_cands + (it.scan_all ? it.k : S.dir_entries[it.k]);
+        ++it.k;
+        const double a = c->q[0] * d.x * d.x + c->q[1] * d.y * d.y + c->q[2] * d.z * d.z +
+                         2.0 * (c->q[3] * d.x * d.y + c->q[4] * d.x * d.z + c->q[5] * d.y * d.z);
+        if (!(fabs(a) <= c->thr)) continue;
+        // walk down to the shape exactly as the traversal would: transforms and group gates
+        const int node = (int)c->visit;
+        int chain[RT_STACK];
+        n = ancestor_chain(S, S.shapes[node].parent, chain);
+        r = ray;
+        bool reachable = true;
+        for (int q = n - 1; q >= 0 && reachable; --q) {
+            const RtShape* __restrict__ g = S.shapes + chain[q];
+            r = transform_ray(g->inv, r);
+            count(cx, ST_RAY_XFORM);
+            if (RT_KIND(g->kind_flags) == RT_GROUP) {
+                const RtGroup* __restrict__ gg = S.groups + g->param;
+                count(cx, ST_GATES);
+                reachable = gg->n_children != 0u && box_intersects(gg->bmin, gg->bmax, r);
+            }
+        }
+        if (reachable) return node;
+    }
+    return -1;
+}
+
 // Sorted intersections of the sibling shapes [begin, end) -- all at nesting level `level0`,
 // whose ray is W.rays[level0] -- merged into the list W.lt/lid[base0, top0).  Entries with
 // t > bound are not recorded (callers pass a bound that leaves a margin wider than every
@@ -301,37 +387,68 @@ template <bool USE_BVH, bool STATS, bool FLAT>
 RT_DEV int list_eval_core(const SceneDev& S, Scratch& W, int begin, int end, int level0, int base0, int top0,
                           double bound, Ctx<STATS, FLAT>& cx) {
     int level = level0;
+    int floor = level0;  // the level whose exhaustion ends the current source (candidate or walk)
     int top = top0;
     int base = base0;  // start of the list entries currently go to
-    Ray ray = W.rays[level0];
-    bool bvh = USE_BVH && level0 == 0 && S.world_bvh_root >= 0;
-    int cur = bvh ? S.world_bvh_root : begin;
-    int lend = end;
-    V3 inv_d = v3(1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z);
+    const Ray ray0 = W.rays[level0];
+    Ray ray = ray0;
+    // with acceleration structures in play, the direction candidates come first, each as a
+    // one-shape pseudo level; then the walk proper (USE_BVH is only used from the world level)
+    bool in_cands = USE_BVH && S.dir_res != 0u;
+    CandIter it;
+    if (USE_BVH && in_cands) cand_begin(S, ray0, it);
+    bool bvh = false;
+    int cur = 0, lend = 0;  // nothing at hand: the first pass through the loop picks a source
+    bool started = false;
+    V3 inv_d = v3(0.0, 0.0, 0.0);
     for (;;) {
         int s = -1;
         if (USE_BVH && bvh) {
-            if (cur >= 0) {
+            while (cur >= 0) {
                 const RtBvhNode* __restrict__ nd = S.bvh + cur;
                 count(cx, ST_BVH_BOX);
-                if (!accel_line_box(nd, ray.o, inv_d, bound)) {
-                    cur = nd->miss;
-                    continue;
-                }
+                const int miss = nd->miss;
                 const int leaf = nd->shape;
-                if (leaf < 0) {
+                if (!accel_line_box(nd, ray.o, inv_d, bound)) {
+                    cur = miss;
+                } else if (leaf < 0) {
                     ++cur;
-                    continue;
+                } else {
+                    s = leaf;
+                    cur = miss;
+                    break;
                 }
-                s = leaf;
-                cur = nd->miss;
             }
         } else if (cur < lend) {
             s = cur;
             cur = (int)S.shapes[s].skip;
         }
         if (s < 0) {  // level exhausted
-            if (level == level0) break;
+            if (level == floor) {
+                if (USE_BVH && in_cands) {  // next direction candidate, or on to the walk
+                    int n;
+                    Ray r;
+                    const int node = cand_next(S, ray0, it, r, n, cx);
+                    if (node >= 0) {
+                        level = floor = n;
+                        ray = r;
+                        bvh = false;
+                        cur = node;
+                        lend = node + 1;
+                        continue;
+                    }
+                    in_cands = false;
+                }
+                if (started) break;
+                started = true;
+                level = floor = level0;
+                ray = ray0;
+                bvh = USE_BVH && S.world_bvh_root >= 0;
+                cur = bvh ? S.world_bvh_root : begin;
+                lend = end;
+                if (USE_BVH && bvh) inv_d = v3(1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z);
+                continue;
+            }
             const int g = W.fnode[level];
             const RtShape* __restrict__ gs = S.shapes + g;
             if (RT_KIND(gs->kind_flags) == RT_CSG) {
@@ -424,11 +541,6 @@ RT_DEV bool accel_box(const RtBvhNode* __restrict__ nd, const V3& o, const V3& i
     return !(t0 > t1) && !(t1 < 0.0) && !(t0 > t_far);
 }
 
-RT_DEV int ancestor_chain(const SceneDev& S, int parent, int* chain) {  // innermost first == the trail
-    int n = 0;
-    for (int p = parent; p >= 0 && n < RT_STACK; p = S.shapes[p].parent) chain[n++] = p;
-    return n;
-}
 
 // One non-group shape `s` met with the ray of its enclosing level (`level` = its nesting depth):
 // a primitive is intersected, a CSG node is materialised through list_eval; the surviving hits go
@@ -467,82 +579,20 @@ RT_DEV bool process_leaf(const SceneDev& S, Scratch& W, int s, const RtShape* __
     return false;
 }
 
-// Direction index (RtDirCand): conics whose "ray parallel to the surface" branch
-// (primitive.rs:486-490, no y-range check) fires for this ray direction must be evaluated
-// whatever the acceleration boxes say.  Calls f(node, shape record, ray at the node's level,
-// level) for each such conic (or its outermost CSG ancestor) that the reference's own group
-// gates let the ray reach; f returns true to stop.  A shape evaluated here and met again by the
-// box walk contributes the same hits twice, which changes nothing.
-template <bool STATS, bool FLAT, class F>
-RT_DEV bool for_each_direction_candidate(const SceneDev& S, const Ray& ray, Ctx<STATS, FLAT>& cx, F&& f) {
-    const V3 d = ray.d;
-    const double len2 = dot(d, d);
-    // the cells are built for unit directions; a shorter direction widens the region
-    const bool scan_all = !(len2 >= 0.999999);
-    uint32_t b = 0, e = S.n_dir_cands;
-    if (!scan_all) {
-        const double ax = fabs(d.x), ay = fabs(d.y), az = fabs(d.z);
-        int face;
-        double m, u, v;
-        if (ax >= ay && ax >= az) {
-            face = d.x >= 0.0 ? 0 : 1, m = ax, u = d.y, v = d.z;
-        } else if (ay >= az) {
-            face = d.y >= 0.0 ? 2 : 3, m = ay, u = d.x, v = d.z;
-        } else {
-            face = d.z >= 0.0 ? 4 : 5, m = az, u = d.x, v = d.y;
-        }
-        const double R = (double)S.dir_res;
-        int i = (int)((u / m + 1.0) * 0.5 * R);
-        int j = (int)((v / m + 1.0) * 0.5 * R);
-        const int hi = (int)S.dir_res - 1;
-        i = i < 0 ? 0 : (i > hi ? hi : i);
-        j = j < 0 ? 0 : (j > hi ? hi : j);
-        const uint32_t cell = ((uint32_t)face * S.dir_res + (uint32_t)j) * S.dir_res + (uint32_t)i;
-        b = S.dir_cell_start[cell];
-        e = S.dir_cell_start[cell + 1];
-    }
-    for (uint32_t k = b; k < e; ++k) {
-        const RtDirCand* __restrict__ c = S.dir_cands + (scan_all ? k : S.dir_entries[k]);
-        const double a = c->q[0] * d.x * d.x + c->q[1] * d.y * d.y + c->q[2] * d.z * d.z +
-                         2.0 * (c->q[3] * d.x * d.y + c->q[4] * d.x * d.z + c->q[5] * d.y * d.z);
-        if (!(fabs(a) <= c->thr)) continue;
-        // walk down to the shape exactly as the traversal would: transforms and group gates
-        const int node = (int)c->visit;
-        const RtShape* __restrict__ sh = S.shapes + node;
-        int chain[RT_STACK];
-        const int n = ancestor_chain(S, sh->parent, chain);
-        Ray r = ray;
-        bool reachable = true;
-        for (int q = n - 1; q >= 0 && reachable; --q) {
-            const RtShape* __restrict__ g = S.shapes + chain[q];
-            r = transform_ray(g->inv, r);
-            count(cx, ST_RAY_XFORM);
-            if (RT_KIND(g->kind_flags) == RT_GROUP) {
-                const RtGroup* __restrict__ gg = S.groups + g->param;
-                count(cx, ST_GATES);
-                reachable = gg->n_children != 0u && box_intersects(gg->bmin, gg->bmax, r);
-            }
-        }
-        if (!reachable) continue;
-        if (f(node, sh, r, n)) return true;
-    }
-    return false;
-}
-
 // World::intersections (world.rs:45-53) as a sorted list at W.lt/lid[0, n), cut at t <= bound.
 template <bool STATS, bool FLAT>
-RT_DEV_COLD int world_list(const SceneDev& S, Scratch& W, const Ray& ray, double bound, Ctx<STATS, FLAT>& cx) {
+RT_DEV int world_list(const SceneDev& S, Scratch& W, const Ray& ray, double bound, Ctx<STATS, FLAT>& cx) {
     int top = 0;
     if constexpr (FLAT) {
         const int n = (int)S.n_shapes;
         for (int s = 0; s < n; ++s) {
-            const RtShape rec = load_uniform(S.shapes + s);
+            const RtShape rec = load_uniform(S.g_shapes + s);
             const unsigned kf = rec.kind_flags;
             const unsigned kind = RT_KIND(kf);
             RtConic conic{0.0, 0.0};
-            if (kind == RT_CYLINDER || kind == RT_CONE) conic = load_uniform(S.conics + rec.param);
+            if (kind == RT_CYLINDER || kind == RT_CONE) conic = load_uniform(S.g_conics + rec.param);
             RtTriangle tri;
-            if (kind == RT_TRIANGLE || kind == RT_SMOOTH_TRIANGLE) tri = load_uniform(S.tris + rec.param);
+            if (kind == RT_TRIANGLE || kind == RT_SMOOTH_TRIANGLE) tri = load_uniform(S.g_tris + rec.param);
             PrimHits h;
             prim_intersect_rec(rec.inv, kf, &conic, &tri, ray, h, cx);
 #pragma unroll
@@ -555,24 +605,6 @@ RT_DEV_COLD int world_list(const SceneDev& S, Scratch& W, const Ray& ray, double
         }
         return top;
     } else {
-    if (S.dir_res != 0u) {
-        for_each_direction_candidate(S, ray, cx, [&](int node, const RtShape* __restrict__ sh, const Ray& r, int n) {
-            const unsigned kf = sh->kind_flags;
-            if (RT_KIND(kf) <= RT_SMOOTH_TRIANGLE) {
-                PrimHits h;
-                prim_intersect(S, sh, kf, r, h, cx);
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (((h.keep >> k) & 1u) && h.t[k] <= bound)
-                        top = list_insert(W, 0, top, h.t[k], (uint32_t)node, cx.status);
-            } else {
-                W.rays[n] = r;
-                const int t2 = list_eval_core<false>(S, W, node, (int)sh->skip, n, top, top, bound, cx);
-                top = list_merge(W, 0, top, t2, cx.status);
-            }
-            return false;
-        });
-    }
     W.rays[0] = ray;
     return list_eval_core<true>(S, W, 0, (int)S.n_shapes, 0, 0, top, bound, cx);
     }
@@ -591,13 +623,13 @@ RT_DEV bool trace(const SceneDev& S, Scratch& W, const Ray& world_ray, bool shad
         bool found = false;
         const int n = (int)S.n_shapes;
         for (int s = 0; s < n; ++s) {
-            const RtShape rec = load_uniform(S.shapes + s);
+            const RtShape rec = load_uniform(S.g_shapes + s);
             const unsigned kf = rec.kind_flags;
             const unsigned kind = RT_KIND(kf);
             RtConic conic{0.0, 0.0};
-            if (kind == RT_CYLINDER || kind == RT_CONE) conic = load_uniform(S.conics + rec.param);
+            if (kind == RT_CYLINDER || kind == RT_CONE) conic = load_uniform(S.g_conics + rec.param);
             RtTriangle tri;
-            if (kind == RT_TRIANGLE || kind == RT_SMOOTH_TRIANGLE) tri = load_uniform(S.tris + rec.param);
+            if (kind == RT_TRIANGLE || kind == RT_SMOOTH_TRIANGLE) tri = load_uniform(S.g_tris + rec.param);
             if (shadow && !(kf & RT_FLAG_HAS_SHADOW)) continue;
             PrimHits h;
             prim_intersect_rec(rec.inv, kf, &conic, &tri, world_ray, h, cx);
@@ -615,16 +647,15 @@ RT_DEV bool trace(const SceneDev& S, Scratch& W, const Ray& world_ray, bool shad
         return found;
     } else {
     int level = 0;
+    int floor = 0;  // level whose exhaustion ends the current source (a direction candidate, or the walk)
     Ray ray = world_ray;
-    bool bvh = S.world_bvh_root >= 0;
-    int cur = bvh ? S.world_bvh_root : 0;
-    int end = (int)S.n_shapes;
-    V3 inv_d = v3(1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z);
-    if (S.dir_res != 0u &&
-        for_each_direction_candidate(S, world_ray, cx, [&](int node, const RtShape* __restrict__ sh, const Ray& r, int n) {
-            return process_leaf(S, W, node, sh, sh->kind_flags, r, n, shadow, limit, best, cx);
-        }))
-        return true;
+    bool in_cands = S.dir_res != 0u;
+    CandIter it;
+    if (in_cands) cand_begin(S, world_ray, it);
+    bool started = false;
+    bool bvh = false;
+    int cur = 0, end = 0;  // nothing at hand: the first pass through the loop picks a source
+    V3 inv_d = v3(0.0, 0.0, 0.0);
     for (;;) {
         int s = -1;
         if (bvh) {
@@ -652,7 +683,31 @@ RT_DEV bool trace(const SceneDev& S, Scratch& W, const Ray& world_ray, bool shad
             cur = (int)S.shapes[s].skip;
         }
         if (s < 0) {  // this level is exhausted
-            if (level == 0) break;
+            if (level == floor) {
+                if (in_cands) {  // next direction candidate as a one-shape pseudo level, or on to the walk
+                    int n;
+                    Ray r;
+                    const int node = cand_next(S, world_ray, it, r, n, cx);
+                    if (node >= 0) {
+                        level = floor = n;
+                        ray = r;
+                        bvh = false;
+                        cur = node;
+                        end = node + 1;
+                        continue;
+                    }
+                    in_cands = false;
+                }
+                if (started) break;
+                started = true;
+                level = floor = 0;
+                ray = world_ray;
+                bvh = S.world_bvh_root >= 0;
+                cur = bvh ? S.world_bvh_root : 0;
+                end = (int)S.n_shapes;
+                if (bvh) inv_d = v3(1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z);
+                continue;
+            }
             --level;
             ray = W.rays[level];
             cur = W.cur[level];
@@ -743,14 +798,14 @@ struct Comps {
 };
 
 // The containers walk of prepare_computations (intersection.rs:50-75) on the full sorted list.
+// The walk stops at the first entry ~equal to the hit; entries this far beyond it cannot
+// influence anything before it (dedupe windows are 1e-5 per nesting level).
+RT_DEV double containers_bound(double hit_t) { return hit_t + 1e-3 + fabs(hit_t) * 1e-9; }
+
+// The containers walk itself on the world list W.lt/lid[0, n).
 template <bool STATS, bool FLAT>
-RT_DEV_COLD void containers_pass(const SceneDev& S, Scratch& W, const Ray& world_ray, double hit_t, double& n1, double& n2,
+RT_DEV void containers_walk(const SceneDev& S, Scratch& W, int n, double hit_t, double& n1, double& n2,
                             Ctx<STATS, FLAT>& cx) {
-    count(cx, ST_CONTAINER_PASSES);
-    // the walk stops at the first entry ~equal to the hit; entries that far beyond it
-    // cannot influence anything before it (dedupe windows are 1e-5 per nesting level)
-    const double bound = hit_t + 1e-3 + fabs(hit_t) * 1e-9;
-    const int n = world_list(S, W, world_ray, bound, cx);
     uint32_t containers[RT_CONTAINERS_CAP];
     int nc = 0;
     n1 = 1.0;
@@ -775,6 +830,14 @@ RT_DEV_COLD void containers_pass(const SceneDev& S, Scratch& W, const Ray& world
             break;
         }
     }
+}
+
+template <bool STATS, bool FLAT>
+RT_DEV void containers_pass(const SceneDev& S, Scratch& W, const Ray& world_ray, double hit_t, double& n1, double& n2,
+                            Ctx<STATS, FLAT>& cx) {
+    count(cx, ST_CONTAINER_PASSES);
+    const int n = world_list(S, W, world_ray, containers_bound(hit_t), cx);
+    containers_walk(S, W, n, hit_t, n1, n2, cx);
 }
 
 template <bool STATS, bool FLAT>
@@ -919,6 +982,8 @@ RT_DEV V3 color_at(const SceneDev& S, Scratch& W, Frame* frames, Ray ray, int re
         hit.idx = -1;
         const bool occluded = trace(S, W, ray, shadow, limit, hit, cx);
         bool have_value = false;
+        bool need_containers = false;
+        double hit_t = 0.0;
         V3 value = v3(0.0, 0.0, 0.0);
         if (shadow) {  // light sd.li is answered (world.rs:58-70)
             const RtLight light = S.lights[sd.li];
@@ -935,7 +1000,7 @@ RT_DEV V3 color_at(const SceneDev& S, Scratch& W, Frame* frames, Ray ray, int re
             // remaining == 0 -- skip the pass where nothing can read it.
             const bool want_n = m.transparency != 0.0 && remaining != 0;
             Comps c;
-            prepare_computations(S, W, ray, hit, want_n, c, cx);
+            prepare_computations(S, W, ray, hit, false, c, cx);
             V3 color = v3(m.color[0], m.color[1], m.color[2]);
             if (m.pattern >= 0) {
                 unsigned nodes = 0;
@@ -944,28 +1009,58 @@ RT_DEV V3 color_at(const SceneDev& S, Scratch& W, Frame* frames, Ray ray, int re
             }
             sd.over = c.over_point, sd.under = c.under_point, sd.eye = c.eye_v, sd.normal = c.normal_v;
             sd.reflect_v = c.reflect_v, sd.color = color, sd.surface = v3(0.0, 0.0, 0.0);
-            sd.n1 = c.n1, sd.n2 = c.n2, sd.mat = (int)sh->material, sd.li = 0u, sd.want_n = want_n ? 1 : 0;
+            sd.n1 = 1.0, sd.n2 = 1.0, sd.mat = (int)sh->material, sd.li = 0u, sd.want_n = want_n ? 1 : 0;
+            need_containers = want_n;
+            hit_t = hit.t;
         }
         bool retrace = false;
         if (!have_value) {
-            // remaining lights: one shadow feeler each
-            while (sd.li < S.n_lights) {
-                const RtLight light = S.lights[sd.li];
-                const V3 lp = v3(light.position[0], light.position[1], light.position[2]);
-                if (S.flags & RT_SCENE_HAS_SHADOWLESS) {  // needs the sorted set: see is_shadowed
-                    const bool in_shadow = is_shadowed(S, W, sd.over, lp, cx);
+            // Work that needs the sorted world set -- the containers walk of a transparent hit, and
+            // shadow tests in scenes with shadowless primitives -- goes through ONE world_list call
+            // site; shadow feelers otherwise go back to the top of the loop to be traced.
+            for (;;) {
+                const bool list_shadow = !need_containers && sd.li < S.n_lights && (S.flags & RT_SCENE_HAS_SHADOWLESS);
+                if (!need_containers && !list_shadow) break;
+                Ray lray = ray;
+                double bound, distance = 0.0;
+                if (need_containers) {
+                    count(cx, ST_CONTAINER_PASSES);
+                    bound = containers_bound(hit_t);
+                } else {
+                    const RtLight light = S.lights[sd.li];
+                    const V3 v = v3(light.position[0], light.position[1], light.position[2]) - sd.over;
+                    distance = magnitude(v);
+                    lray = Ray{sd.over, normalize(v)};
+                    bound = distance + 1e-3 + distance * 1e-9;
+                    count(cx, ST_RAY_SHADOW);
+                }
+                const int n = world_list(S, W, lray, bound, cx);
+                if (need_containers) {
+                    containers_walk(S, W, n, hit_t, sd.n1, sd.n2, cx);
+                    need_containers = false;
+                } else {
+                    bool in_shadow = false;  // first shadow-casting entry with t >= 0 (intersection.rs:154-158)
+                    for (int j = 0; j < n; ++j) {
+                        const double t = W.lt[j];
+                        if (t >= 0.0 && (S.shapes[W.lid[j]].kind_flags & RT_FLAG_HAS_SHADOW)) {
+                            in_shadow = t < distance;
+                            break;
+                        }
+                    }
+                    const RtLight light = S.lights[sd.li];
                     const RtMaterial m = S.mats[sd.mat];
                     sd.surface = sd.surface + lighting(m, sd.color, light, sd.over, sd.eye, sd.normal, in_shadow, cx);
                     ++sd.li;
-                    continue;
                 }
-                const V3 v = lp - sd.over;  // world.rs:86-89
+            }
+            if (sd.li < S.n_lights) {  // next light: one shadow feeler (world.rs:86-89)
+                const RtLight light = S.lights[sd.li];
+                const V3 v = v3(light.position[0], light.position[1], light.position[2]) - sd.over;
                 limit = magnitude(v);
                 ray = Ray{sd.over, normalize(v)};
                 shadow = true;
                 count(cx, ST_RAY_SHADOW);
                 retrace = true;
-                break;
             }
         }
         if (retrace) continue;
