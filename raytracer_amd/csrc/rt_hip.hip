@@ -13,6 +13,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "rt_trace.h"
@@ -20,7 +21,7 @@
 using namespace rtd;
 
 #ifndef RT_STAGE_MAX_BYTES
-#define RT_STAGE_MAX_BYTES 32768u  // LDS image of a small scene's tables (160 KB of LDS per CU, 2 blocks resident)
+#define RT_STAGE_MAX_BYTES 16384u  // table image; with the 48 KB LDS list the block stays within 64 KB of dynamic LDS
 #endif
 #ifndef RT_WAVES_PER_SIMD_FLAT
 #define RT_WAVES_PER_SIMD_FLAT 2
@@ -92,7 +93,9 @@ __global__ __launch_bounds__(256, FLAT ? RT_WAVES_PER_SIMD_FLAT : RT_WAVES_PER_S
         active = y < cam.vsize;
     }
     if (active) {
-        Scratch W;
+        // STAGED scenes are small enough for the per-lane sorted list to live in LDS too
+        typename std::conditional<STAGED, ScratchLds, Scratch>::type W;
+        if constexpr (STAGED) W.attach(rt_lds + ((S_in.stage_bytes + 15u) & ~15u), threadIdx.x);
         Frame frames[RT_MAX_DEPTH + 1];
         const Ray ray = ray_for_pixel(cam, x, y);
         count(cx, ST_RAY_PRIMARY);
@@ -383,7 +386,8 @@ int launch_render(const RtScene* scene, const RtCameraDesc* cam, uint32_t depth,
     const bool flat = (scene->dev.flags & RT_SCENE_FLAT) != 0;
     const bool staged = flat && scene->dev.stage_bytes != 0;
     auto go = [&](auto kernel) {
-        hipLaunchKernelGGL(kernel, grid, block, staged ? scene->dev.stage_bytes : 0u, stream, scene->dev, *cam, (int)depth,
+        const unsigned lds = staged ? ((scene->dev.stage_bytes + 15u) & ~15u) + RT_LDS_LIST_BYTES : 0u;
+        hipLaunchKernelGGL(kernel, grid, block, lds, stream, scene->dev, *cam, (int)depth,
                            rows, d_out, d_stats, scene->d_status);
     };
     if (d_stats)
@@ -521,7 +525,9 @@ int rt_hip_scene_create(const RtSceneDesc* desc, RtScene** out) {
         put(desc->materials, sizeof(RtMaterial) * desc->n_materials, &s->dev.stage_off[2]);
         put(desc->patterns, sizeof(RtPattern) * desc->n_patterns, &s->dev.stage_off[3]);
         put(desc->lights, sizeof(RtLight) * desc->n_lights, &s->dev.stage_off[4]);
-        if (!image.empty() && image.size() <= RT_STAGE_MAX_BYTES) {
+        uint64_t world_hits = 0;  // most entries World::intersections can return: the per-lane list must hold them
+        for (uint32_t i = 0; i < desc->n_shapes; ++i) world_hits += max_hits_of_kind(RT_KIND(desc->shapes[i].kind_flags));
+        if (!image.empty() && image.size() <= RT_STAGE_MAX_BYTES && world_hits <= RT_LDS_LIST_CAP) {
             unsigned char* d_image = nullptr;
             rc = upload(image.data(), image.size(), &d_image);
             if (d_image) s->allocations.push_back(d_image);

@@ -92,14 +92,40 @@ RT_DEV void count(Ctx<STATS, FLAT>& cx, int what, unsigned n = 1) {
 // Per-lane working memory (private segment; lanes of a wave interleave, so equal
 // indices coalesce).  Levels are absolute nesting depths, shared by the
 // streaming traversal and the list evaluator it calls for CSG nodes.
-struct Scratch {
+struct LevelState {
     Ray rays[RT_STACK];   // ray in the local space of the compound open at each level
     int cur[RT_STACK];    // streaming traversal: saved cursor
     int end[RT_STACK];    //   linear scan: end index; -2: the level walks a BVH
     int fnode[RT_STACK];  // list evaluator: compound open at each level
     int fbase[RT_STACK];  //   start of its accumulated list
+};
+// ... with the sorted hit list and the containers set in private memory (any scene)
+struct Scratch : LevelState {
     double lt[RT_LIST_CAP];
     uint32_t lid[RT_LIST_CAP];
+    uint32_t ct[RT_LIST_CAP];
+    RT_DEV double& LT(int i) { return lt[i]; }
+    RT_DEV uint32_t& LID(int i) { return lid[i]; }
+    RT_DEV uint32_t& CT(int i) { return ct[i]; }
+    RT_DEV int cap() const { return RT_LIST_CAP; }
+};
+// ... or in LDS, for small scenes whose world list provably fits RT_LDS_LIST_CAP entries:
+// entry i of lane l sits at [i][l], so a wave's accesses to one entry are conflict-free.
+#define RT_LDS_LIST_CAP 12
+#define RT_LDS_LIST_BYTES (256u * RT_LDS_LIST_CAP * 16u)  // per 256-thread block: t (8) + id (4) + container (4)
+struct ScratchLds : LevelState {
+    double* lt;
+    uint32_t* lid;
+    uint32_t* ct;
+    RT_DEV void attach(unsigned char* block_base, unsigned tid) {
+        lt = reinterpret_cast<double*>(block_base) + tid;
+        lid = reinterpret_cast<uint32_t*>(block_base + 256u * RT_LDS_LIST_CAP * 8u) + tid;
+        ct = reinterpret_cast<uint32_t*>(block_base + 256u * RT_LDS_LIST_CAP * 12u) + tid;
+    }
+    RT_DEV double& LT(int i) { return lt[i * 256]; }
+    RT_DEV uint32_t& LID(int i) { return lid[i * 256]; }
+    RT_DEV uint32_t& CT(int i) { return ct[i * 256]; }
+    RT_DEV int cap() const { return RT_LDS_LIST_CAP; }
 };
 
 // ---- one primitive's own hit set ----------------------------------------------
@@ -221,43 +247,46 @@ RT_DEV void prim_intersect(const SceneDev& S, const RtShape* __restrict__ sh, un
 // BTreeSet::append of one element (Q1): on a bit-equal t the entry of the shape that comes
 // later in depth-first order survives (a linear scan inserts in that order anyway; a walk
 // through an acceleration structure does not, hence the explicit comparison).
-RT_DEV int list_insert(Scratch& W, int base, int top, double t, uint32_t id, unsigned& status) {
+template <class SW>
+RT_DEV int list_insert(SW& W, int base, int top, double t, uint32_t id, unsigned& status) {
     int pos = top;
-    while (pos > base && W.lt[pos - 1] > t) --pos;
-    if (pos > base && W.lt[pos - 1] == t) {
-        if (id > W.lid[pos - 1]) W.lid[pos - 1] = id;
+    while (pos > base && W.LT(pos - 1) > t) --pos;
+    if (pos > base && W.LT(pos - 1) == t) {
+        if (id > W.LID(pos - 1)) W.LID(pos - 1) = id;
         return top;
     }
-    if (top >= RT_LIST_CAP) {
+    if (top >= W.cap()) {
         status |= RT_STATUS_LIST_OVERFLOW;
         return top;
     }
     for (int j = top; j > pos; --j) {
-        W.lt[j] = W.lt[j - 1];
-        W.lid[j] = W.lid[j - 1];
+        W.LT(j) = W.LT(j - 1);
+        W.LID(j) = W.LID(j - 1);
     }
-    W.lt[pos] = t;
-    W.lid[pos] = id;
+    W.LT(pos) = t;
+    W.LID(pos) = id;
     return top + 1;
 }
 // self.append(other) for two adjacent runs [a,b) and [b,c): returns the new top.
-RT_DEV int list_merge(Scratch& W, int a, int b, int c, unsigned& status) {
+template <class SW>
+RT_DEV int list_merge(SW& W, int a, int b, int c, unsigned& status) {
     if (a == b) return c;
     int top = b;
     for (int r = b; r < c; ++r) {
-        const double t = W.lt[r];
-        const uint32_t id = W.lid[r];
+        const double t = W.LT(r);
+        const uint32_t id = W.LID(r);
         top = list_insert(W, a, top, t, id, status);
     }
     return top;
 }
 // Operation::filter_intersections (compound.rs:142-168) in place on [b, top), then the
 // `.collect()` dedupe (Q2).  `g` is the CSG node's shape index.
-RT_DEV int csg_filter(const SceneDev& S, Scratch& W, int b, int top, int g, unsigned op, unsigned lhit_offset) {
+template <class SW>
+RT_DEV int csg_filter(const SceneDev& S, SW& W, int b, int top, int g, unsigned op, unsigned lhit_offset) {
     bool in_l = false, in_r = false;
     int k = b;
     for (int j = b; j < top; ++j) {
-        const uint32_t id = W.lid[j];
+        const uint32_t id = W.LID(j);
         const bool l_hit = S.lhit[lhit_offset + (id - (uint32_t)g - 1u)] != 0;
         bool allowed;  // compound.rs:175-181
         if (op == 0u)
@@ -271,16 +300,16 @@ RT_DEV int csg_filter(const SceneDev& S, Scratch& W, int b, int top, int g, unsi
         else
             in_r = !in_r;
         if (allowed) {
-            W.lt[k] = W.lt[j];
-            W.lid[k] = id;
+            W.LT(k) = W.LT(j);
+            W.LID(k) = id;
             ++k;
         }
     }
     int m = b;
     for (int j = b; j < k; ++j) {
-        if (j + 1 < k && t_eq(W.lt[j], W.lt[j + 1])) continue;
-        W.lt[m] = W.lt[j];
-        W.lid[m] = W.lid[j];
+        if (j + 1 < k && t_eq(W.LT(j), W.LT(j + 1))) continue;
+        W.LT(m) = W.LT(j);
+        W.LID(m) = W.LID(j);
         ++m;
     }
     return m;
@@ -383,8 +412,8 @@ RT_DEV int cand_next(const SceneDev& S, const Ray& ray, CandIter& it, Ray& r, in
 // through it (groups inside CSG nodes never carry one: see the flattener).
 // Shape::intersect / Compound::local_intersect / World::intersections
 // (shape.rs:28-32, compound.rs:87-117, world.rs:45-53).
-template <bool USE_BVH, bool STATS, bool FLAT>
-RT_DEV int list_eval_core(const SceneDev& S, Scratch& W, int begin, int end, int level0, int base0, int top0,
+template <bool USE_BVH, bool STATS, bool FLAT, class SW>
+RT_DEV int list_eval_core(const SceneDev& S, SW& W, int begin, int end, int level0, int base0, int top0,
                           double bound, Ctx<STATS, FLAT>& cx) {
     int level = level0;
     int floor = level0;  // the level whose exhaustion ends the current source (candidate or walk)
@@ -511,8 +540,8 @@ RT_DEV int list_eval_core(const SceneDev& S, Scratch& W, int begin, int end, int
 }
 
 // A compound subtree evaluated on its own (CSG nodes met by the streaming traversal).
-template <bool STATS, bool FLAT>
-RT_DEV_COLD int list_eval(const SceneDev& S, Scratch& W, int begin, int end, int level0, int base0, double bound,
+template <bool STATS, bool FLAT, class SW>
+RT_DEV_COLD int list_eval(const SceneDev& S, SW& W, int begin, int end, int level0, int base0, double bound,
                      Ctx<STATS, FLAT>& cx) {
     return list_eval_core<false>(S, W, begin, end, level0, base0, base0, bound, cx);
 }
@@ -546,8 +575,8 @@ RT_DEV bool accel_box(const RtBvhNode* __restrict__ nd, const V3& o, const V3& i
 // a primitive is intersected, a CSG node is materialised through list_eval; the surviving hits go
 // to the closest-hit reduction or, for a shadow feeler, to the "anything before the light" test.
 // Returns true when a shadow hit was found.
-template <bool STATS, bool FLAT>
-RT_DEV bool process_leaf(const SceneDev& S, Scratch& W, int s, const RtShape* __restrict__ sh, unsigned kf,
+template <bool STATS, bool FLAT, class SW>
+RT_DEV bool process_leaf(const SceneDev& S, SW& W, int s, const RtShape* __restrict__ sh, unsigned kf,
                          const Ray& ray, int level, bool shadow, double limit, Best& best, Ctx<STATS, FLAT>& cx) {
     if (RT_KIND(kf) <= RT_SMOOTH_TRIANGLE) {
         if (shadow && !(kf & RT_FLAG_HAS_SHADOW)) return false;
@@ -568,8 +597,8 @@ RT_DEV bool process_leaf(const SceneDev& S, Scratch& W, int s, const RtShape* __
     W.rays[level] = ray;
     const int n = list_eval(S, W, s, (int)sh->skip, level, 0, __builtin_inf(), cx);
     for (int j = 0; j < n; ++j) {
-        const double t = W.lt[j];
-        const int id = (int)W.lid[j];
+        const double t = W.LT(j);
+        const int id = (int)W.LID(j);
         if (shadow) {
             if ((S.shapes[id].kind_flags & RT_FLAG_HAS_SHADOW) && t >= 0.0 && t < limit) return true;
         } else {
@@ -580,8 +609,8 @@ RT_DEV bool process_leaf(const SceneDev& S, Scratch& W, int s, const RtShape* __
 }
 
 // World::intersections (world.rs:45-53) as a sorted list at W.lt/lid[0, n), cut at t <= bound.
-template <bool STATS, bool FLAT>
-RT_DEV int world_list(const SceneDev& S, Scratch& W, const Ray& ray, double bound, Ctx<STATS, FLAT>& cx) {
+template <bool STATS, bool FLAT, class SW>
+RT_DEV int world_list(const SceneDev& S, SW& W, const Ray& ray, double bound, Ctx<STATS, FLAT>& cx) {
     int top = 0;
     if constexpr (FLAT) {
         const int n = (int)S.n_shapes;
@@ -614,8 +643,8 @@ RT_DEV int world_list(const SceneDev& S, Scratch& W, const Ray& ray, double boun
 // intersection.rs:154-158).  shadow == true: returns true as soon as a shadow-casting
 // primitive is met at 0 <= t < limit (world.rs:85-96).  Colour rays and shadow feelers share
 // this one loop so that the lanes of a wave stay together whatever each one is tracing.
-template <bool STATS, bool FLAT>
-RT_DEV bool trace(const SceneDev& S, Scratch& W, const Ray& world_ray, bool shadow, double limit, Best& best,
+template <bool STATS, bool FLAT, class SW>
+RT_DEV bool trace(const SceneDev& S, SW& W, const Ray& world_ray, bool shadow, double limit, Best& best,
                   Ctx<STATS, FLAT>& cx) {
     if constexpr (FLAT) {
         // only primitives, no acceleration structure: every lane walks the same shape sequence,
@@ -803,45 +832,44 @@ struct Comps {
 RT_DEV double containers_bound(double hit_t) { return hit_t + 1e-3 + fabs(hit_t) * 1e-9; }
 
 // The containers walk itself on the world list W.lt/lid[0, n).
-template <bool STATS, bool FLAT>
-RT_DEV void containers_walk(const SceneDev& S, Scratch& W, int n, double hit_t, double& n1, double& n2,
+template <bool STATS, bool FLAT, class SW>
+RT_DEV void containers_walk(const SceneDev& S, SW& W, int n, double hit_t, double& n1, double& n2,
                             Ctx<STATS, FLAT>& cx) {
-    uint32_t containers[RT_CONTAINERS_CAP];
     int nc = 0;
     n1 = 1.0;
     n2 = 1.0;
     for (int j = 0; j < n; ++j) {
-        const bool is_self = t_eq(W.lt[j], hit_t);
-        const uint32_t id = W.lid[j];
-        if (is_self && nc > 0) n1 = S.mats[S.shapes[containers[nc - 1]].material].refractive_index;
+        const bool is_self = t_eq(W.LT(j), hit_t);
+        const uint32_t id = W.LID(j);
+        if (is_self && nc > 0) n1 = S.mats[S.shapes[W.CT(nc - 1)].material].refractive_index;
         int pos = -1;
         for (int k = 0; k < nc; ++k)
-            if (containers[k] == id && pos < 0) pos = k;
+            if (W.CT(k) == id && pos < 0) pos = k;
         if (pos >= 0) {
-            for (int k = pos; k + 1 < nc; ++k) containers[k] = containers[k + 1];
+            for (int k = pos; k + 1 < nc; ++k) W.CT(k) = W.CT(k + 1);
             --nc;
-        } else if (nc < RT_CONTAINERS_CAP) {
-            containers[nc++] = id;
+        } else if (nc < W.cap()) {
+            W.CT(nc++) = id;
         } else {
             cx.status |= RT_STATUS_LIST_OVERFLOW;
         }
         if (is_self) {
-            if (nc > 0) n2 = S.mats[S.shapes[containers[nc - 1]].material].refractive_index;
+            if (nc > 0) n2 = S.mats[S.shapes[W.CT(nc - 1)].material].refractive_index;
             break;
         }
     }
 }
 
-template <bool STATS, bool FLAT>
-RT_DEV void containers_pass(const SceneDev& S, Scratch& W, const Ray& world_ray, double hit_t, double& n1, double& n2,
+template <bool STATS, bool FLAT, class SW>
+RT_DEV void containers_pass(const SceneDev& S, SW& W, const Ray& world_ray, double hit_t, double& n1, double& n2,
                             Ctx<STATS, FLAT>& cx) {
     count(cx, ST_CONTAINER_PASSES);
     const int n = world_list(S, W, world_ray, containers_bound(hit_t), cx);
     containers_walk(S, W, n, hit_t, n1, n2, cx);
 }
 
-template <bool STATS, bool FLAT>
-RT_DEV void prepare_computations(const SceneDev& S, Scratch& W, const Ray& ray, const Best& hit, bool want_n1n2,
+template <bool STATS, bool FLAT, class SW>
+RT_DEV void prepare_computations(const SceneDev& S, SW& W, const Ray& ray, const Best& hit, bool want_n1n2,
                                  Comps& c, Ctx<STATS, FLAT>& cx) {
     count(cx, ST_HITS_SHADED);
     const RtShape* __restrict__ sh = S.shapes + hit.idx;
@@ -884,8 +912,8 @@ RT_DEV double schlick(const Comps& c) {  // intersection.rs:182-200
 }
 
 // World::is_shadowed (world.rs:85-96)
-template <bool STATS, bool FLAT>
-RT_DEV bool is_shadowed(const SceneDev& S, Scratch& W, V3 point, V3 light_position, Ctx<STATS, FLAT>& cx) {
+template <bool STATS, bool FLAT, class SW>
+RT_DEV bool is_shadowed(const SceneDev& S, SW& W, V3 point, V3 light_position, Ctx<STATS, FLAT>& cx) {
     const V3 v = light_position - point;
     const double distance = magnitude(v);
     const Ray r{point, normalize(v)};
@@ -896,8 +924,8 @@ RT_DEV bool is_shadowed(const SceneDev& S, Scratch& W, V3 point, V3 light_positi
         const double bound = distance + 1e-3 + distance * 1e-9;  // margin: see containers_pass
         const int n = world_list(S, W, r, bound, cx);
         for (int j = 0; j < n; ++j) {
-            const double t = W.lt[j];
-            if (t >= 0.0 && (S.shapes[W.lid[j]].kind_flags & RT_FLAG_HAS_SHADOW)) return t < distance;
+            const double t = W.LT(j);
+            if (t >= 0.0 && (S.shapes[W.LID(j)].kind_flags & RT_FLAG_HAS_SHADOW)) return t < distance;
         }
         return false;
     }
@@ -946,8 +974,8 @@ RT_DEV V3 combine(V3 surface, V3 reflected, V3 refracted, bool use_schlick, doub
     return (surface + reflected) + refracted;
 }
 
-template <bool STATS, bool FLAT>
-RT_DEV bool find_hit(const SceneDev& S, Scratch& W, const Ray& ray, Best& best, Ctx<STATS, FLAT>& cx) {
+template <bool STATS, bool FLAT, class SW>
+RT_DEV bool find_hit(const SceneDev& S, SW& W, const Ray& ray, Best& best, Ctx<STATS, FLAT>& cx) {
     best.t = __builtin_inf();
     best.idx = -1;
     trace(S, W, ray, false, 0.0, best, cx);
@@ -967,8 +995,8 @@ struct Shade {
 // One loop iteration traces ONE ray per lane -- a colour ray (primary, reflected, refracted) or
 // a shadow feeler -- and then advances that lane's shade_hit state machine; the wave never
 // splits into "lanes tracing shadows" and "lanes tracing colour rays".
-template <bool STATS, bool FLAT>
-RT_DEV V3 color_at(const SceneDev& S, Scratch& W, Frame* frames, Ray ray, int remaining, Ctx<STATS, FLAT>& cx) {
+template <bool STATS, bool FLAT, class SW>
+RT_DEV V3 color_at(const SceneDev& S, SW& W, Frame* frames, Ray ray, int remaining, Ctx<STATS, FLAT>& cx) {
     int sp = 0;
     bool shadow = false;
     double limit = 0.0;
@@ -1041,8 +1069,8 @@ RT_DEV V3 color_at(const SceneDev& S, Scratch& W, Frame* frames, Ray ray, int re
                 } else {
                     bool in_shadow = false;  // first shadow-casting entry with t >= 0 (intersection.rs:154-158)
                     for (int j = 0; j < n; ++j) {
-                        const double t = W.lt[j];
-                        if (t >= 0.0 && (S.shapes[W.lid[j]].kind_flags & RT_FLAG_HAS_SHADOW)) {
+                        const double t = W.LT(j);
+                        if (t >= 0.0 && (S.shapes[W.LID(j)].kind_flags & RT_FLAG_HAS_SHADOW)) {
                             in_shadow = t < distance;
                             break;
                         }
