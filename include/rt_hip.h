@@ -265,6 +265,12 @@ void rt_hip_scene_destroy(RtScene* scene);
 int rt_hip_render(const RtSceneDesc* desc, const RtCameraDesc* cam, uint32_t depth, double* out_rgb,
                   RtStats* stats);
 
+/* `Camera::render(&world)` followed by the per-channel rule of `Canvas::to_ppm` (camera.rs:51-66 +
+ * canvas.rs:85-90): the frame is quantised on the device and only the 8-bit samples cross PCIe.
+ * out_rgb8[vsize*hsize*3] is a HOST buffer, index = (y*hsize + x)*3 + channel.  `stats` may be NULL. */
+int rt_hip_render_rgb8(const RtSceneDesc* desc, const RtCameraDesc* cam, uint32_t depth, uint8_t* out_rgb8,
+                       RtStats* stats);
+
 /* Same path with everything resident: renders a subset of image rows of a
  * device-resident scene into DEVICE memory, asynchronously on `hip_stream`
  * (a hipStream_t, NULL = default stream).  Local row k (0 <= k < n_local_rows)

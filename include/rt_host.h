@@ -113,6 +113,9 @@ typedef struct RthCamera {
 int rth_camera_desc(const RthCamera* cam, RtCameraDesc* out);
 /* Camera::render(&world) ON THE GPU (camera.rs:51): out_rgb[v*h*3] host buffer. */
 int rth_camera_render(const RthCamera* cam, const RthWorld* w, double* out_rgb, RtStats* stats_or_null);
+/* Camera::render(&world) + Canvas::scale_to_ppm_data per channel (camera.rs:51, canvas.rs:85), quantised on
+ * the device: out_rgb8[v*h*3] host buffer. */
+int rth_camera_render_rgb8(const RthCamera* cam, const RthWorld* w, uint8_t* out_rgb8, RtStats* stats_or_null);
 
 /* ---- flattened scene, for callers that keep it resident -------------------- */
 RthFlat* rth_world_flatten(const RthWorld* w, int build_bvh);
@@ -122,6 +125,8 @@ void rth_flat_free(RthFlat* f);
 /* ---- Canvas (src/graphics/canvas.rs) ---------------------------------------- */
 size_t rth_canvas_to_ppm(const double* rgb, size_t width, size_t height, char* out, size_t cap); /* canvas.rs:46 */
 void rth_canvas_quantize(const double* rgb, size_t n_values, uint8_t* out);  /* canvas.rs:85 */
+/* Canvas::to_ppm (canvas.rs:46-83) from samples that are already 8-bit.  Returns the text length; writes <= cap. */
+size_t rth_ppm_from_rgb8(const uint8_t* rgb8, size_t width, size_t height, char* out, size_t cap);
 
 /* ---- exercises (the reference's exercises/ programs) + synthetic scene ---------------------------- */
 /* name: plane scene pattern glass_bubble teapot hexagon csg cover room synthetic */

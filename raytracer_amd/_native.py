@@ -143,7 +143,8 @@ class RthCamera(C.Structure):
 
 # Every symbol include/rt_hip.h declares (checked by tests/test_capi_symbols.py).
 HIP_SYMBOLS = ["rt_hip_init", "rt_hip_shutdown", "rt_hip_strerror", "rt_hip_last_hip_error", "rt_hip_scene_create",
-               "rt_hip_scene_destroy", "rt_hip_scene_status", "rt_hip_render", "rt_hip_render_rows", "rt_hip_color_at",
+               "rt_hip_scene_destroy", "rt_hip_scene_status", "rt_hip_render", "rt_hip_render_rgb8", "rt_hip_render_rows",
+               "rt_hip_color_at",
                "rt_hip_probe", "rt_hip_quantize"]
 
 _vp = C.c_void_p
@@ -165,6 +166,8 @@ _sig(hip, "rt_hip_scene_destroy", None, _vp)
 _sig(hip, "rt_hip_scene_status", C.c_int, _vp, _vp)
 _sig(hip, "rt_hip_render", C.c_int, C.POINTER(RtSceneDesc), C.POINTER(RtCameraDesc), C.c_uint32, c_double_p,
      C.POINTER(RtStats))
+_sig(hip, "rt_hip_render_rgb8", C.c_int, C.POINTER(RtSceneDesc), C.POINTER(RtCameraDesc), C.c_uint32,
+     C.POINTER(C.c_uint8), C.POINTER(RtStats))
 _sig(hip, "rt_hip_render_rows", C.c_int, _vp, C.POINTER(RtCameraDesc), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
      C.c_uint32, _vp, _vp, _vp)
 _sig(hip, "rt_hip_color_at", C.c_int, _vp, c_double_p, C.c_uint32, C.c_uint32, c_double_p)
@@ -224,10 +227,12 @@ _sig(host, "rth_world_probe", C.c_int, _vp, c_double_p, C.c_uint32, c_double_p)
 _sig(host, "rth_world_describe", C.c_size_t, _vp, c_double_p, C.c_size_t)
 _sig(host, "rth_camera_desc", C.c_int, C.POINTER(RthCamera), C.POINTER(RtCameraDesc))
 _sig(host, "rth_camera_render", C.c_int, C.POINTER(RthCamera), _vp, c_double_p, C.POINTER(RtStats))
+_sig(host, "rth_camera_render_rgb8", C.c_int, C.POINTER(RthCamera), _vp, C.POINTER(C.c_uint8), C.POINTER(RtStats))
 _sig(host, "rth_world_flatten", _vp, _vp, C.c_int)
 _sig(host, "rth_flat_desc", C.POINTER(RtSceneDesc), _vp)
 _sig(host, "rth_flat_free", None, _vp)
 _sig(host, "rth_canvas_to_ppm", C.c_size_t, c_double_p, C.c_size_t, C.c_size_t, C.c_char_p, C.c_size_t)
+_sig(host, "rth_ppm_from_rgb8", C.c_size_t, C.POINTER(C.c_uint8), C.c_size_t, C.c_size_t, C.c_char_p, C.c_size_t)
 _sig(host, "rth_canvas_quantize", None, c_double_p, C.c_size_t, C.POINTER(C.c_uint8))
 _sig(host, "rth_exercise", C.c_int, C.c_char_p, C.c_size_t, C.c_size_t, C.c_char_p, C.POINTER(_vp),
      C.POINTER(RthCamera))

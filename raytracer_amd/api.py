@@ -315,6 +315,16 @@ class Canvas:
         with open(path, "wb") as f:
             f.write(self.to_ppm())
 
+    @staticmethod
+    def ppm_from_rgb8(rgb8):
+        """Canvas::to_ppm (canvas.rs:46-83) from uint8 samples [h, w, 3] that scale_to_ppm_data already produced."""
+        src = np.ascontiguousarray(rgb8, dtype=np.uint8)
+        h, w = src.shape[0], src.shape[1]
+        p = src.ctypes.data_as(C.POINTER(C.c_uint8))
+        buf = np.empty(64 + h * w * 12, dtype=np.uint8)  # header + at most 4 bytes per sample: one formatting pass
+        n = N.host.rth_ppm_from_rgb8(p, w, h, buf.ctypes.data_as(C.c_char_p), buf.size)
+        return buf[:n].tobytes()
+
 
 class World(_Handle):
     """src/raytracer/world.rs:17-43,130-145"""
@@ -445,6 +455,18 @@ class Camera:
                 "Camera::render")
         canvas = Canvas(self.h_size, self.v_size, out)
         return (canvas, st) if stats else canvas
+
+    def render_rgb8(self, world):
+        """`render(world)` + scale_to_ppm_data per channel (canvas.rs:85-90) on the device -> uint8 [v, h, 3]."""
+        out = np.empty((self.v_size, self.h_size, 3), dtype=np.uint8)
+        cc = self._c()
+        N.check(N.host.rth_camera_render_rgb8(C.byref(cc), world._p, out.ctypes.data_as(C.POINTER(C.c_uint8)), None),
+                "Camera::render")
+        return out
+
+    def render_ppm(self, world):
+        """`camera.render(&world).to_ppm()` as bytes; only the 8-bit samples leave the device."""
+        return Canvas.ppm_from_rgb8(self.render_rgb8(world))
 
 
 class obj:

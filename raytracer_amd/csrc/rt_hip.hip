@@ -575,8 +575,10 @@ int rt_hip_render_rows(const RtScene* scene, const RtCameraDesc* cam, uint32_t d
     return launch_render(scene, cam, depth, rows, d_out_rgb, static_cast<hipStream_t>(hip_stream), d_stats);
 }
 
-int rt_hip_render(const RtSceneDesc* desc, const RtCameraDesc* cam, uint32_t depth, double* out_rgb, RtStats* stats) {
-    if (!out_rgb) return RT_ERR_INVALID_ARG;
+// Camera::render with the frame returned as f64 colours (out_rgb) or as the 8-bit samples Canvas::to_ppm prints (out_rgb8)
+static int render_to_host(const RtSceneDesc* desc, const RtCameraDesc* cam, uint32_t depth, double* out_rgb,
+                          uint8_t* out_rgb8, RtStats* stats) {
+    if (!out_rgb && !out_rgb8) return RT_ERR_INVALID_ARG;
     int rc = check_camera(cam, depth);
     if (rc != RT_OK) return rc;
     RtScene* scene = nullptr;
@@ -584,10 +586,12 @@ int rt_hip_render(const RtSceneDesc* desc, const RtCameraDesc* cam, uint32_t dep
     if (rc != RT_OK) return rc;
     const size_t n_values = (size_t)cam->hsize * cam->vsize * 3u;
     double* d_out = nullptr;
+    uint8_t* d_out8 = nullptr;
     RtStats* d_stats = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     auto body = [&]() -> int {
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_out), n_values * sizeof(double)));
+        if (out_rgb8) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_out8), n_values));
         if (stats) {
             HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_stats), sizeof(RtStats)));
             HIP_TRY(hipMemset(d_stats, 0, sizeof(RtStats)));
@@ -599,7 +603,12 @@ int rt_hip_render(const RtSceneDesc* desc, const RtCameraDesc* cam, uint32_t dep
         const int lrc = launch_render(scene, cam, depth, rows, d_out, nullptr, d_stats);
         if (lrc != RT_OK) return lrc;
         if (stats) HIP_TRY(hipEventRecord(e1, nullptr));
-        HIP_TRY(hipMemcpy(out_rgb, d_out, n_values * sizeof(double), hipMemcpyDeviceToHost));
+        if (out_rgb8) {  // quantise on the device: an eighth of the bytes cross PCIe
+            const int qrc = rt_hip_quantize(d_out, n_values, d_out8, nullptr);
+            if (qrc != RT_OK) return qrc;
+            HIP_TRY(hipMemcpy(out_rgb8, d_out8, n_values, hipMemcpyDeviceToHost));
+        }
+        if (out_rgb) HIP_TRY(hipMemcpy(out_rgb, d_out, n_values * sizeof(double), hipMemcpyDeviceToHost));
         const int src = read_status(scene, nullptr);
         if (stats) {
             HIP_TRY(hipMemcpy(stats, d_stats, sizeof(RtStats), hipMemcpyDeviceToHost));
@@ -614,9 +623,21 @@ int rt_hip_render(const RtSceneDesc* desc, const RtCameraDesc* cam, uint32_t dep
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
     if (d_out) (void)hipFree(d_out);
+    if (d_out8) (void)hipFree(d_out8);
     if (d_stats) (void)hipFree(d_stats);
     rt_hip_scene_destroy(scene);
     return rc;
+}
+
+int rt_hip_render(const RtSceneDesc* desc, const RtCameraDesc* cam, uint32_t depth, double* out_rgb, RtStats* stats) {
+    if (!out_rgb) return RT_ERR_INVALID_ARG;
+    return render_to_host(desc, cam, depth, out_rgb, nullptr, stats);
+}
+
+int rt_hip_render_rgb8(const RtSceneDesc* desc, const RtCameraDesc* cam, uint32_t depth, uint8_t* out_rgb8,
+                       RtStats* stats) {
+    if (!out_rgb8) return RT_ERR_INVALID_ARG;
+    return render_to_host(desc, cam, depth, nullptr, out_rgb8, stats);
 }
 
 int rt_hip_color_at(const RtScene* scene, const double* rays, uint32_t n, uint32_t depth, double* out_rgb) {

@@ -25,10 +25,9 @@ int main(int argc, char** argv) {
     try {
         rt::Exercise e = rt::build_exercise(name, width, height, resources);
         const auto t0 = std::chrono::steady_clock::now();
-        const rt::Canvas canvas = e.camera.render(e.world);
+        e.camera.render_to_file(e.world, out);  // camera.render(&world).write_ppm(path), quantised on the device
         const auto t1 = std::chrono::steady_clock::now();
-        canvas.write_ppm(out);
-        std::printf("%s %zux%zu rendered in %.2f ms -> %s\n", name.c_str(), width, height,
+        std::printf("%s %zux%zu rendered and written in %.2f ms -> %s\n", name.c_str(), width, height,
                     std::chrono::duration<double, std::milli>(t1 - t0).count(), out.c_str());
     } catch (const std::exception& ex) {
         std::fprintf(stderr, "%s: %s\n", name.c_str(), ex.what());

@@ -293,6 +293,23 @@ int rth_camera_render(const RthCamera* cam, const RthWorld* w, double* out_rgb, 
     });
 }
 
+int rth_camera_render_rgb8(const RthCamera* cam, const RthWorld* w, uint8_t* out_rgb8, RtStats* stats) {
+    return guard_int([&] {
+        const Camera camera = make_camera(*cam);
+        const FlatScene flat = flatten(w->w);
+        const RtSceneDesc desc = flat.desc();
+        const RtCameraDesc cd = camera_desc(camera);
+        const int rc = rt_hip_render_rgb8(&desc, &cd, Camera::kDepth, out_rgb8, stats);
+        if (rc != RT_OK) {
+            std::string msg = std::string("Camera::render: ") + rt_hip_strerror(rc);
+            const char* hip = rt_hip_last_hip_error();
+            if (hip && *hip) msg += std::string(" (") + hip + ")";
+            throw RenderError(rc, msg);
+        }
+        return 0;
+    });
+}
+
 RthFlat* rth_world_flatten(const RthWorld* w, int build_bvh) {
     return guard([&] {
         FlattenOptions opt;
@@ -311,6 +328,9 @@ size_t rth_canvas_to_ppm(const double* rgb, size_t width, size_t height, char* o
     const std::string s = Canvas(width, height, std::move(px)).to_ppm();
     if (out) std::memcpy(out, s.data(), s.size() < cap ? s.size() : cap);
     return s.size();
+}
+size_t rth_ppm_from_rgb8(const uint8_t* rgb8, size_t width, size_t height, char* out, size_t cap) {
+    return Canvas::ppm_from_rgb8_into(width, height, rgb8, out, cap);
 }
 void rth_canvas_quantize(const double* rgb, size_t n_values, uint8_t* out) {
     for (size_t i = 0; i < n_values; ++i) out[i] = Canvas::scale_to_ppm_data(rgb[i]);

@@ -3,6 +3,9 @@
 // flatten + one call through the C ABI of include/rt_hip.h.  There is no CPU
 // path here: if the HIP library reports an error (no device included) the call
 // throws rt::RenderError.
+#include <fstream>
+#include <memory>
+#include <stdexcept>
 #include <string>
 
 #include "rt_flatten.h"
@@ -27,6 +30,32 @@ Canvas Camera::render(const World& world) const {
     const int rc = rt_hip_render(&desc, &cam, kDepth, reinterpret_cast<double*>(pixels.data()), nullptr);
     if (rc != RT_OK) fail(rc, "Camera::render");
     return Canvas(h_size_, v_size_, std::move(pixels));
+}
+
+std::string Camera::render_ppm(const World& world) const {
+    const FlatScene flat = flatten(world);
+    const RtSceneDesc desc = flat.desc();
+    const RtCameraDesc cam = camera_desc(*this);
+    std::vector<uint8_t> rgb8(h_size_ * v_size_ * 3);
+    const int rc = rt_hip_render_rgb8(&desc, &cam, kDepth, rgb8.data(), nullptr);
+    if (rc != RT_OK) fail(rc, "Camera::render_ppm");
+    return Canvas::ppm_from_rgb8(h_size_, v_size_, rgb8.data());
+}
+
+void Camera::render_to_file(const World& world, const std::string& path) const {
+    const FlatScene flat = flatten(world);
+    const RtSceneDesc desc = flat.desc();
+    const RtCameraDesc cam = camera_desc(*this);
+    std::vector<uint8_t> rgb8(h_size_ * v_size_ * 3);
+    const int rc = rt_hip_render_rgb8(&desc, &cam, kDepth, rgb8.data(), nullptr);
+    if (rc != RT_OK) fail(rc, "Camera::render");
+    const size_t cap = 64 + rgb8.size() * 4;  // header + at most "255 " per sample
+    std::unique_ptr<char[]> text(new char[cap]);  // not zero-filled: the writer's threads touch the pages first
+    const size_t n = Canvas::ppm_from_rgb8_into(h_size_, v_size_, rgb8.data(), text.get(), cap);
+    std::ofstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error("file should be written successfully: " + path);
+    f.write(text.get(), static_cast<std::streamsize>(n));
+    if (!f) throw std::runtime_error("file should be written successfully: " + path);
 }
 
 std::vector<Color> World::color_at(const std::vector<Ray>& rays, uint8_t remaining_recursions) const {

@@ -6,8 +6,10 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <fstream>
 #include <sstream>
+#include <thread>
 #include <unordered_map>
 
 namespace rt {
@@ -263,35 +265,114 @@ uint8_t Canvas::scale_to_ppm_data(double c) {
     if (v > 255.0) v = 255.0;
     return static_cast<uint8_t>(std::round(v));  // half away from zero, like f64::round
 }
-std::string Canvas::to_ppm() const {
-    std::string out = "P3\n" + std::to_string(width_) + " " + std::to_string(height_) + "\n255\n";
-    out.reserve(out.size() + pixels_.size() * 12);
-    char tok[8];
-    for (size_t row = 0; row < height_; ++row) {
-        // canvas.rs:68-79: a token joins the current line while the running sum of
-        // (token length + 1) stays <= 70; the sum restarts with each line.
-        size_t line_len = 0;
-        bool first = true;
-        for (size_t x = 0; x < width_; ++x) {
-            const Color& c = pixels_[row * width_ + x];
-            const uint8_t ch[3] = {scale_to_ppm_data(c.red), scale_to_ppm_data(c.green),
-                                   scale_to_ppm_data(c.blue)};
-            for (uint8_t v : ch) {
-                const int n = std::snprintf(tok, sizeof tok, "%u", static_cast<unsigned>(v));
-                if (!first && line_len + n + 1 > 70) {
-                    out.push_back('\n');
-                    line_len = 0;
-                    first = true;
-                }
-                if (!first) out.push_back(' ');
-                out.append(tok, n);
-                line_len += n + 1;
-                first = false;
-            }
+namespace {
+// decimal text of 0..255, one trailing separator slot: the formatter copies 4 bytes per token
+struct ByteText {
+    char text[256][4];
+    uint8_t len[256];
+    ByteText() {
+        for (int v = 0; v < 256; ++v) {
+            const int n = std::snprintf(text[v], 4, "%d", v);
+            len[v] = static_cast<uint8_t>(n);
+            for (int k = n; k < 4; ++k) text[v][k] = ' ';
         }
-        if (width_ > 0) out.push_back('\n');
     }
+};
+const ByteText& byte_text() {
+    static const ByteText t;
+    return t;
+}
+// canvas.rs:68-79 for one image row: a token joins the current line while the running sum of
+// (token length + 1) stays <= 70; the sum restarts with each line.  Returns the end of the output;
+// with dst == nullptr only counts.
+char* format_row(const uint8_t* row, size_t n_tokens, char* dst, size_t* count) {
+    const ByteText& bt = byte_text();
+    size_t line_len = 0, total = 0;
+    for (size_t i = 0; i < n_tokens; ++i) {
+        const uint8_t v = row[i];
+        const size_t n = bt.len[v];
+        char sep = ' ';
+        if (line_len + n + 1 > 70 && line_len != 0) {
+            sep = '\n';
+            line_len = 0;
+        }
+        if (dst) {
+            if (i != 0) *dst++ = sep;
+            // 4-byte copy: the slack is overwritten by the next token; the last token of a row must not
+            // spill into the next row's bytes (another thread may own them)
+            std::memcpy(dst, bt.text[v], i + 1 < n_tokens ? 4 : n);
+            dst += n;
+        }
+        total += n + (i != 0 ? 1 : 0);
+        line_len += n + 1;
+    }
+    if (n_tokens > 0) {
+        if (dst) *dst++ = '\n';
+        ++total;
+    }
+    if (count) *count = total;
+    return dst;
+}
+}  // namespace
+
+namespace {
+// lays the text out (pass 1), asks `place(total)` where it goes (nullptr: nowhere) and writes it (pass 2)
+template <class Place>
+size_t ppm_build(size_t width, size_t height, const uint8_t* rgb8, Place&& place) {
+    const std::string header = "P3\n" + std::to_string(width) + " " + std::to_string(height) + "\n255\n";
+    const size_t n_tokens = width * 3;
+    unsigned n_threads = std::thread::hardware_concurrency();
+    if (n_threads == 0) n_threads = 1;
+    if (n_threads > 16) n_threads = 16;
+    if (height * n_tokens < (1u << 20)) n_threads = 1;
+    auto for_rows = [&](auto&& fn) {  // contiguous row ranges: each thread touches its own pages of the output
+        if (n_threads == 1) {
+            for (size_t y = 0; y < height; ++y) fn(y);
+            return;
+        }
+        std::vector<std::thread> pool;
+        const size_t chunk = (height + n_threads - 1) / n_threads;
+        for (unsigned t = 0; t < n_threads; ++t)
+            pool.emplace_back([&, t] {
+                const size_t y1 = std::min(height, (t + 1) * chunk);
+                for (size_t y = t * chunk; y < y1; ++y) fn(y);
+            });
+        for (std::thread& th : pool) th.join();
+    };
+    // pass 1: the byte count of every row (rows are independent: the line budget restarts per row)
+    std::vector<size_t> offset(height + 1, 0);
+    for_rows([&](size_t y) { format_row(rgb8 + y * n_tokens, n_tokens, nullptr, &offset[y + 1]); });
+    for (size_t y = 0; y < height; ++y) offset[y + 1] += offset[y];
+    const size_t total = header.size() + offset[height];
+    char* out = place(total);
+    if (!out) return total;
+    // pass 2: every row straight into its final position
+    std::memcpy(out, header.data(), header.size());
+    char* body = out + header.size();
+    for_rows([&](size_t y) { format_row(rgb8 + y * n_tokens, n_tokens, body + offset[y], nullptr); });
+    return total;
+}
+}  // namespace
+
+size_t Canvas::ppm_from_rgb8_into(size_t width, size_t height, const uint8_t* rgb8, char* out, size_t cap) {
+    return ppm_build(width, height, rgb8, [&](size_t total) { return out && total <= cap ? out : nullptr; });
+}
+std::string Canvas::ppm_from_rgb8(size_t width, size_t height, const uint8_t* rgb8) {
+    std::string out;
+    ppm_build(width, height, rgb8, [&](size_t total) {
+        out.resize(total);
+        return &out[0];
+    });
     return out;
+}
+std::string Canvas::to_ppm() const {
+    std::vector<uint8_t> rgb8(pixels_.size() * 3);
+    for (size_t i = 0; i < pixels_.size(); ++i) {
+        rgb8[i * 3 + 0] = scale_to_ppm_data(pixels_[i].red);
+        rgb8[i * 3 + 1] = scale_to_ppm_data(pixels_[i].green);
+        rgb8[i * 3 + 2] = scale_to_ppm_data(pixels_[i].blue);
+    }
+    return ppm_from_rgb8(width_, height_, rgb8.data());
 }
 void Canvas::write_ppm(const std::string& path) const {
     std::ofstream f(path, std::ios::binary);

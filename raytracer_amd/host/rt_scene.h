@@ -237,6 +237,10 @@ public:
     size_t height() const { return height_; }
     const std::vector<Color>& pixels() const { return pixels_; }
     std::string to_ppm() const;                 // canvas.rs:46-83
+    // the same text from samples already quantised by scale_to_ppm_data (e.g. on the device): rgb8[height*width*3]
+    static std::string ppm_from_rgb8(size_t width, size_t height, const uint8_t* rgb8);
+    // ... written into out[cap] when it fits; returns the length of the text either way
+    static size_t ppm_from_rgb8_into(size_t width, size_t height, const uint8_t* rgb8, char* out, size_t cap);
     void write_ppm(const std::string& path) const;  // canvas.rs:40-44
     static uint8_t scale_to_ppm_data(double c);  // canvas.rs:85-90
 
@@ -281,6 +285,10 @@ public:
     Camera(size_t h_size, size_t v_size, double field_of_view);
     Camera with_transform(const Matrix4& t) const;
     Canvas render(const World& world) const;  // camera.rs:51 -- runs on the GPU
+    // `camera.render(&world).to_ppm()` (camera.rs:51 + canvas.rs:46) with the quantisation done on the device:
+    // byte-identical text, an eighth of the device-to-host traffic, no f64 canvas on the host
+    std::string render_ppm(const World& world) const;
+    void render_to_file(const World& world, const std::string& path) const;  // ... .write_ppm(path) (canvas.rs:40)
 
     size_t h_size() const { return h_size_; }
     size_t v_size() const { return v_size_; }

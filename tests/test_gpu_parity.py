@@ -49,6 +49,22 @@ def test_default_world_center_pixel():
     assert np.allclose(img.pixel_at(5, 5), (0.38066, 0.47583, 0.2855), atol=1e-4)
 
 
+@pytest.mark.parametrize("name,width,height", [("pattern", 517, 271), ("cover", 300, 170), ("csg", 200, 101)])
+def test_render_ppm_is_the_text_of_the_rendered_canvas(name, width, height):
+    """`camera.render(&world).to_ppm()` with the quantisation done on the device (rt_hip_render_rgb8)
+    is byte-identical to the reference writer (canvas.rs:46-90, restated in oracle/) applied to the f64
+    frame of the same device render, and the 8-bit samples equal the oracle frame's up to the stated bar."""
+    world, cam = rt.exercise(name, width, height)
+    frame = cam.render(world).pixels
+    rgb8 = cam.render_rgb8(world)
+    assert np.array_equal(rgb8, orc.quantize(frame))
+    text = cam.render_ppm(world)
+    assert text == orc.to_ppm(frame)
+    ref, _ = orc.OracleWorld(world.describe()).render(cam)
+    dq = np.abs(rgb8.astype(int) - orc.quantize(ref).astype(int)).max(axis=-1)
+    assert (dq > 1).sum() == 0 and (dq > 0).sum() <= 1e-3 * dq.size
+
+
 def test_synthetic_matches_oracle():
     world, cam = rt.synthetic(256, 144, 2000)
     gpu = cam.render(world).pixels

@@ -140,6 +140,18 @@ def test_canvas_ppm_layout():  # canvas.rs:125-203
     assert np.array_equal(rt.Canvas(33, 7, px).quantized(), orc.quantize(px))
 
 
+@pytest.mark.parametrize("w,h", [(0, 0), (1, 1), (5, 0), (6, 1), (17, 3), (24, 5), (33, 7), (701, 611)])
+def test_ppm_from_rgb8_matches_the_oracle_writer(w, h):  # canvas.rs:46-83, incl. the threaded two-pass path
+    rng = np.random.default_rng(w * 1000 + h)
+    # mixed token widths so the 70-column breaks fall everywhere: runs of 1-, 2- and 3-digit samples
+    q = rng.choice(np.array([0, 7, 9, 10, 42, 99, 100, 128, 255], dtype=np.uint8), size=(h, w, 3))
+    text = rt.Canvas.ppm_from_rgb8(q)
+    assert text == orc.to_ppm(q.astype(np.float64) / 255.0)
+    assert all(len(line) <= 70 for line in text.split(b"\n"))
+    if w and h:
+        assert np.array_equal(np.array(text.split()[4:], dtype=np.int64), q.reshape(-1))
+
+
 def test_obj_parser():  # obj.rs:187-350
     with pytest.raises(RuntimeError, match="no shapes found"):   # obj.rs:47: gibberish alone yields no shape
         rt.obj.parse_string("There was a young lady named Bright\nwho traveled much faster than light.\n")

@@ -1,14 +1,33 @@
-"""PCIe-inclusive rate of the host-buffer entry point (rt_hip_render): scene upload + kernel + D2H."""
+"""PCIe-inclusive rates of the host-buffer entry points: scene upload + kernel + D2H, as f64 colours
+(rt_hip_render) and as 8-bit samples quantised on the device (rt_hip_render_rgb8), plus the host P3 writer."""
 import sys, time
 sys.path.insert(0, '.')
+import numpy as np
 import raytracer_amd as rt
+from oracle import orc
+
+def best(fn, n=3):
+    ts = []
+    for _ in range(n):
+        t = time.perf_counter(); out = fn(); ts.append(time.perf_counter() - t)
+    return min(ts), out
+
 for name in ("pattern", "glass_bubble"):
     world, cam = rt.exercise(name, 4096, 2160)
     cam.render(world)  # warm-up
-    ts = []
-    for _ in range(3):
-        t = time.perf_counter(); img, st = cam.render(world, stats=True); ts.append(time.perf_counter() - t)
+    t, (img, st) = best(lambda: cam.render(world, stats=True))
     rays = st.rays_primary + st.rays_shadow + st.rays_reflect + st.rays_refract
-    t = min(ts)
     print(f"{name} 4096x2160 via rt_hip_render (host in/out, counting kernel): {t*1e3:.1f} ms wall, kernel {st.kernel_ms:.2f} ms, "
           f"{rays/t/1e6:.0f} Mrays/s PCIe-inclusive (212 MB framebuffer D2H to pageable memory)")
+    t8, rgb8 = best(lambda: cam.render_rgb8(world))
+    print(f"{name} 4096x2160 via rt_hip_render_rgb8 (device quantise, 26.5 MB D2H): {t8*1e3:.1f} ms wall, "
+          f"{rays/t8/1e6:.0f} Mrays/s PCIe-inclusive")
+    tq, q = best(lambda: img.quantized(), 1)
+    assert np.array_equal(q, rgb8)
+    tf, text = best(lambda: rt.Canvas.ppm_from_rgb8(rgb8))
+    to, ref = best(lambda: orc.to_ppm(img.pixels), 1)
+    assert text == ref
+    print(f"  P3 text ({len(text)/1e6:.1f} MB): table-driven threaded writer {tf*1e3:.1f} ms; reference-style per-token "
+          f"formatting of the f64 canvas (oracle port, 1 thread) {to*1e3:.1f} ms; host quantise alone {tq*1e3:.1f} ms")
+    tp, _ = best(lambda: cam.render_ppm(world))
+    print(f"  camera.render(&world).to_ppm() end to end: {tp*1e3:.1f} ms")
