@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--primitives", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--print-stats", action="store_true", help="event counters of one frame to stderr")
+    ap.add_argument("--depth", type=int, default=5, help="recursion budget (camera.rs:59 uses 5; other values are for studies)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle sample")
     return ap.parse_args()
 
@@ -89,7 +90,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
 
     def render(d_stats=None):
-        scene.render_rows(cd, rt.Camera.DEPTH, rank, n_parts, band, my_rows, shard.data_ptr(), stream, d_stats)
+        scene.render_rows(cd, args.depth, rank, n_parts, band, my_rows, shard.data_ptr(), stream, d_stats)
 
     def step():
         render()
@@ -167,7 +168,7 @@ def main():
             "config": {
                 "workload": f"exercises/{args.workload}.rs" if args.workload != "synthetic"
                 else f"synthetic cover/room-style, {args.primitives} primitives, seed 0x5EED5EED",
-                "width": W, "height": H, "depth": rt.Camera.DEPTH, "band_rows": band,
+                "width": W, "height": H, "depth": args.depth, "band_rows": band,
                 "parallelism": f"row-bands x{n_parts}" + (" + RCCL gather to rank 0" if n_parts > 1 else ""),
                 "rays_per_frame": int(rays_per_frame), "mpixels_per_s": round(W * H * args.steps / elapsed / 1e6, 3),
             },

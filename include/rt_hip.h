@@ -284,6 +284,19 @@ int rt_hip_render_rows(const RtScene* scene, const RtCameraDesc* cam, uint32_t d
                        uint32_t n_parts, uint32_t band_rows, uint32_t n_local_rows,
                        double* d_out_rgb, void* hip_stream, RtStats* d_stats);
 
+/* How launches on this scene organise color_at's recursion (world.rs:98-127); the image is the same
+ * either way, bit for bit.  mode 1: one launch per generation of rays -- a hit that needs reflected /
+ * refracted colours parks itself in a node pool and queues its child rays, later launches fold the
+ * children's colours back (dense waves at every depth); mode 0: one launch, every lane keeps the
+ * whole ray tree of its pixel; mode -1 (default): the library chooses (mode 1 for scenes of >= 1024
+ * shapes with an acceleration structure in which some material is reflective or transparent: the
+ * generations cost ~400 B of queue traffic per ray, which small scenes do not earn back).  queue_items / node_items: capacities of one generation's ray queue
+ * and of the node pool, 0 = default (2 and 3 per pixel of the frame); when they run out the affected
+ * hits fall back to mode-0 behaviour.  The workspace (64 B per queue item, two queues; 128 B per
+ * node) belongs to the scene and is allocated by the first launch that needs it.
+ * Replaces: nothing in the reference (tuning). */
+int rt_hip_scene_set_wavefront(RtScene* scene, int mode, uint64_t queue_items, uint64_t node_items);
+
 /* Run-time conditions raised by launches on this scene since the last call (RT_ERR_LIST_OVERFLOW,
  * RT_ERR_NAN_T) or RT_OK; synchronises `hip_stream` and clears them.  The blocking entry points
  * call this themselves; rt_hip_render_rows is asynchronous and leaves it to the caller.

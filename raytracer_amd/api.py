@@ -412,6 +412,10 @@ class DeviceScene:
                                          C.c_void_p(d_out_ptr), C.c_void_p(stream or 0), C.c_void_p(d_stats_ptr or 0)),
                 "rt_hip_render_rows")
 
+    def set_wavefront(self, mode=-1, queue_items=0, node_items=0):
+        """rt_hip_scene_set_wavefront: -1 by policy, 0 one launch, 1 one launch per generation of rays."""
+        N.check(N.hip.rt_hip_scene_set_wavefront(self._p, mode, queue_items, node_items), "rt_hip_scene_set_wavefront")
+
     def status(self, stream=None):
         N.check(N.hip.rt_hip_scene_status(self._p, C.c_void_p(stream or 0)), "rt_hip_scene_status")
 

@@ -10,6 +10,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -106,6 +107,130 @@ __global__ __launch_bounds__(256, FLAT ? RT_WAVES_PER_SIMD_FLAT : RT_WAVES_PER_S
         o[2] = c.z;
     }
     flush_stats(cx, stats, status);
+}
+
+// One generation of colour rays (see "wave-front organisation" in rt_trace.h).  PRIMARY: generation
+// 0, rays from the camera, pixel tiles as in render_kernel.  Otherwise generation g > 0, rays from the
+// queue slices generation g - 1 filled, whose lengths only the device knows: block b strides over
+// slice b % RT_WF_SHARDS together with the other blocks of that slice.
+// (Nothing the cold no-room path needs is kept in registers across color_at: it re-reads its item,
+// or the camera record from the workspace.)
+template <bool STATS, bool FLAT, bool STAGED, bool PRIMARY>
+__global__ __launch_bounds__(256, FLAT ? RT_WAVES_PER_SIMD_FLAT : RT_WAVES_PER_SIMD) void wf_level_kernel(
+    const SceneDev S_in, RtCameraDesc cam, int depth, RowMap rows, double* __restrict__ out, RtStats* __restrict__ stats,
+    unsigned* __restrict__ status, WfSpace ws, unsigned level) {
+    SceneDev S = S_in;
+    if constexpr (STAGED) {
+        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(S_in.stage);
+        uint4* dst = reinterpret_cast<uint4*>(rt_lds);
+        for (unsigned i = threadIdx.x; i < S_in.stage_bytes / 16u; i += blockDim.x) dst[i] = src[i];
+        __syncthreads();
+        S.shapes = reinterpret_cast<const RtShape*>(rt_lds + S_in.stage_off[0]);
+        S.conics = reinterpret_cast<const RtConic*>(rt_lds + S_in.stage_off[1]);
+        S.mats = reinterpret_cast<const RtMaterial*>(rt_lds + S_in.stage_off[2]);
+        S.pats = reinterpret_cast<const RtPattern*>(rt_lds + S_in.stage_off[3]);
+        S.lights = reinterpret_cast<const RtLight*>(rt_lds + S_in.stage_off[4]);
+    }
+    Ctx<STATS, FLAT> cx;
+    cx.status = 0;
+    if constexpr (STATS) {
+#pragma unroll
+        for (int i = 0; i < ST_COUNT; ++i) cx.cnt[i] = 0;
+    }
+    typename std::conditional<STAGED, ScratchLds, Scratch>::type W;
+    if constexpr (STAGED) W.attach(rt_lds + ((S_in.stage_bytes + 15u) & ~15u), threadIdx.x);
+    Frame frames[RT_MAX_DEPTH + 1];
+    const unsigned out_shard = ((blockIdx.y * gridDim.x + blockIdx.x) * 4u + (threadIdx.x >> 6)) % RT_WF_SHARDS;  // per wave
+    // One pass of one item: color_at up to the end of the lane's first shade_hit, then -- the wave
+    // together -- its children into the next generation's queue, or its colour to whoever waits for it.
+    // Returns false when the lane found no room and has to go again with `pending.open` cleared.
+    WfPending pending;
+    pending.open = true;
+    auto pass = [&](bool active, const Ray& ray, int remaining, uint32_t parent) -> bool {
+        bool deferred = false;
+        Shade sd;
+        V3 c = v3(0.0, 0.0, 0.0);
+        const Ctx<STATS, FLAT> before = cx;
+        if (active && PRIMARY) count(cx, ST_RAY_PRIMARY);
+        if (active) c = color_at(S, W, frames, ray, remaining, cx, pending, deferred, sd);
+        Children ch;
+        ch.do_reflect = ch.do_refract = ch.use_schlick = false;
+        double reflective = 0.0, transparency = 0.0;
+        bool want = false;
+        if (active && deferred) {
+            const RtMaterial m = S.mats[sd.mat];
+            reflective = m.reflective, transparency = m.transparency;
+            shade_children(m, sd, Ray{sd.over, sd.reflect_v}, remaining, ch, cx);
+            want = ch.do_reflect || ch.do_refract;
+            if (!want) c = combine(sd.surface, v3(0.0, 0.0, 0.0), v3(0.0, 0.0, 0.0), ch.use_schlick, ch.reflectance);
+        }
+        const bool placed = wf_commit(ws, out_shard, level, want, parent, sd.surface, reflective, transparency, ch, sd.over,
+                                      sd.reflect_v, remaining - 1);
+        if (want && !placed) {  // no room: forget this pass, the next one keeps the subtree
+            const unsigned flags = cx.status;
+            cx = before;
+            cx.status |= flags;
+            pending.open = false;
+            return false;
+        }
+        if (placed) {
+            if (ch.do_reflect) count(cx, ST_RAY_REFLECT);
+            if (ch.do_refract) count(cx, ST_RAY_REFRACT);
+        } else if (active) {
+            wf_deliver(ws.nodes, out, parent, c);
+        }
+        pending.open = true;
+        return true;
+    };
+    if constexpr (PRIMARY) {
+        const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+        const unsigned x = blockIdx.x * 16u + (wave & 1u) * 8u + (lane & 7u);
+        const unsigned k = blockIdx.y * 16u + (wave >> 1) * 8u + (lane >> 3);
+        bool active = x < cam.hsize && k < rows.n_local_rows;
+        unsigned y = 0;
+        if (active) {
+            y = ((k / rows.band_rows) * rows.n_parts + rows.part) * rows.band_rows + k % rows.band_rows;
+            active = y < cam.vsize;
+        }
+        while (__builtin_amdgcn_ballot_w64(active) != 0ull) {  // at most twice
+            // (the camera record is read from the workspace so that it need not stay in registers)
+            const Ray ray = active ? ray_for_pixel(*ws.cam, x, y) : Ray{v3(0.0, 0.0, 0.0), v3(0.0, 0.0, 1.0)};
+            if (pass(active, ray, depth, RT_WF_PIXEL | (k * ws.cam->hsize + x))) active = false;
+        }
+    } else {
+        const unsigned in_shard = blockIdx.x % RT_WF_SHARDS;
+        const unsigned n_items = wf_items_of(ws, in_shard, level);
+        const unsigned stride = (gridDim.x / RT_WF_SHARDS) * 256u;
+        const WfItem* q_in = ws.queue[level & 1u] + (size_t)in_shard * ws.q_cap;
+        unsigned i = (blockIdx.x / RT_WF_SHARDS) * 256u + threadIdx.x;
+        while (i < n_items) {
+            const WfItem* it = q_in + i;
+            if (pass(it->remaining != RT_WF_EMPTY, it->ray, (int)it->remaining, it->parent)) i += stride;
+        }
+    }
+    flush_stats(cx, stats, status);
+}
+
+// generation g is traced: its nodes end here, generation g + 1's begin
+__global__ void wf_mark_kernel(WfSpace ws, unsigned level) {
+    WfShard& sh = ws.shards[threadIdx.x];
+    const unsigned long long end = (unsigned long long)sh.node_begin[level] + (sh.asked[level] & 0xffffffffull);
+    sh.node_begin[level + 1u] = end < ws.node_cap ? (unsigned)end : ws.node_cap;
+}
+
+// shade_hit's last line for every node of generation g (world.rs:76-82), children first
+__global__ __launch_bounds__(256) void wf_combine_kernel(WfSpace ws, unsigned level, double* __restrict__ out) {
+    const unsigned shard = blockIdx.x % RT_WF_SHARDS;
+    const WfShard& sh = ws.shards[shard];
+    const unsigned begin = sh.node_begin[level], end = sh.node_begin[level + 1u];
+    const WfNode* __restrict__ nodes = ws.nodes + (size_t)shard * ws.node_cap;
+    for (unsigned i = begin + (blockIdx.x / RT_WF_SHARDS) * 256u + threadIdx.x; i < end; i += (gridDim.x / RT_WF_SHARDS) * 256u) {
+        const WfNode n = nodes[i];
+        if (n.flags & WF_DEAD) continue;
+        const V3 reflected = (n.flags & WF_HAS_REFLECT) ? n.child[0] * n.reflective : v3(0.0, 0.0, 0.0);
+        const V3 refracted = (n.flags & WF_HAS_REFRACT) ? n.child[1] * n.transparency : v3(0.0, 0.0, 0.0);
+        wf_deliver(ws.nodes, out, n.parent, combine(n.surface, reflected, refracted, (n.flags & WF_USE_SCHLICK) != 0u, n.reflectance));
+    }
 }
 
 template <bool FLAT>
@@ -354,6 +479,12 @@ struct RtScene {
     unsigned* d_status;
     int device;
     std::vector<void*> allocations;
+    // wave-front workspace (queues, node pool, counters), sized by the largest frame rendered so far;
+    // launches on one scene are not re-entrant, so it is simply reused
+    mutable WfSpace wf;
+    mutable size_t wf_pixels;
+    int wf_mode;                       // rt_hip_scene_set_wavefront: -1 by policy, 0 never, 1 whenever the scene can recurse
+    size_t wf_q_items, wf_node_items;  // capacities asked for (0: the defaults, per pixel of the frame)
 };
 
 namespace {
@@ -378,6 +509,63 @@ int read_status(const RtScene* scene, hipStream_t stream) {
     return status_to_error(flags);
 }
 
+#ifndef RT_WF_GRID
+#define RT_WF_GRID 8192u  // blocks striding over a queue whose length only the device knows
+#endif
+#ifndef RT_WF_MIN_SHAPES
+#define RT_WF_MIN_SHAPES 1024u  // scenes below this stay with the one-launch kernel (see launch_render)
+#endif
+#ifndef RT_WF_QUEUE_PER_PIXEL
+#define RT_WF_QUEUE_PER_PIXEL 2u  // queue slots per generation and node slots per frame, in units of the frame's pixels;
+#define RT_WF_NODES_PER_PIXEL 3u  // past that a hit keeps its subtree to itself (slower, same result)
+#endif
+
+// RT_HIP_WAVEFRONT=0/1 in the environment overrides the policy for scenes left at "by policy" (experiments)
+int wavefront_env() {
+    static const int v = [] {
+        const char* e = std::getenv("RT_HIP_WAVEFRONT");
+        return e && *e ? std::atoi(e) : -1;
+    }();
+    return v;
+}
+
+int ensure_wavefront_space(const RtScene* scene, size_t pixels) {
+    if (scene->wf.shards && scene->wf_pixels >= pixels) return RT_OK;
+    if (scene->wf.shards) {  // grow: launches of one scene are ordered by the caller, the old space is idle by contract
+        HIP_TRY(hipDeviceSynchronize());
+        for (void* p : {(void*)scene->wf.queue[0], (void*)scene->wf.queue[1], (void*)scene->wf.nodes, (void*)scene->wf.shards})
+            if (p) (void)hipFree(p);
+        std::memset(&scene->wf, 0, sizeof scene->wf);
+        scene->wf_pixels = 0;
+    }
+    // capacities are per shard; at least one wave's worth each, so that a tiny frame is not all refusals
+    const size_t q_items = scene->wf_q_items ? scene->wf_q_items : pixels * RT_WF_QUEUE_PER_PIXEL;
+    const size_t node_items = scene->wf_node_items ? scene->wf_node_items : pixels * RT_WF_NODES_PER_PIXEL;
+    size_t q_cap = (q_items + RT_WF_SHARDS - 1) / RT_WF_SHARDS, node_cap = (node_items + RT_WF_SHARDS - 1) / RT_WF_SHARDS;
+    if (!scene->wf_q_items && q_cap < 128) q_cap = 128;
+    if (!scene->wf_node_items && node_cap < 64) node_cap = 64;
+    if (node_cap * RT_WF_SHARDS >= 0x40000000ull || q_cap * RT_WF_SHARDS >= 0x80000000ull) return RT_ERR_INVALID_ARG;
+    WfSpace w{};
+    auto body = [&]() -> int {
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.queue[0]), q_cap * RT_WF_SHARDS * sizeof(WfItem)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.queue[1]), q_cap * RT_WF_SHARDS * sizeof(WfItem)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.nodes), node_cap * RT_WF_SHARDS * sizeof(WfNode)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.shards), RT_WF_SHARDS * sizeof(WfShard) + sizeof(RtCameraDesc)));
+        w.cam = reinterpret_cast<const RtCameraDesc*>(w.shards + RT_WF_SHARDS);
+        return RT_OK;
+    };
+    const int rc = body();
+    if (rc != RT_OK) {
+        for (void* p : {(void*)w.queue[0], (void*)w.queue[1], (void*)w.nodes, (void*)w.shards})
+            if (p) (void)hipFree(p);
+        return rc;
+    }
+    w.q_cap = (unsigned)q_cap, w.node_cap = (unsigned)node_cap;
+    scene->wf = w;
+    scene->wf_pixels = pixels;
+    return RT_OK;
+}
+
 int launch_render(const RtScene* scene, const RtCameraDesc* cam, uint32_t depth, const RowMap& rows, double* d_out,
                   hipStream_t stream, RtStats* d_stats) {
     const dim3 block(256);
@@ -385,8 +573,46 @@ int launch_render(const RtScene* scene, const RtCameraDesc* cam, uint32_t depth,
     if (grid.y > 65535u * 16u) return RT_ERR_INVALID_ARG;
     const bool flat = (scene->dev.flags & RT_SCENE_FLAT) != 0;
     const bool staged = flat && scene->dev.stage_bytes != 0;
+    const unsigned lds = staged ? ((scene->dev.stage_bytes + 15u) & ~15u) + RT_LDS_LIST_BYTES : 0u;
+    // Large scenes whose materials can spawn reflected / refracted rays are traced one generation of rays per
+    // launch (dense waves at every depth); the others in one launch, each lane keeping its pixel.  The
+    // generations cost ~400 B of queue and node traffic per colour ray, which only pays where a ray is
+    // expensive and the lanes of a wave drift apart: measured at 4096x2160, 10 000 primitives 135 -> 95 ms,
+    // but cover.rs (30 primitives) 9.1 -> 15.7 ms and glass_bubble.rs 5.5 -> 10.2 ms.
+    const size_t pixels = (size_t)cam->hsize * rows.n_local_rows;
+    const bool can_wavefront = (scene->dev.flags & RT_SCENE_RECURSIVE) != 0 && depth > 0 && pixels < 0x20000000ull;
+    const int mode = scene->wf_mode >= 0 ? scene->wf_mode : wavefront_env();
+    const bool wavefront = can_wavefront && (mode == 1 || (mode < 0 && !flat && scene->dev.n_shapes >= RT_WF_MIN_SHAPES));
+    if (wavefront) {
+        const int rc = ensure_wavefront_space(scene, pixels);
+        if (rc != RT_OK) return rc;
+        const WfSpace ws = scene->wf;
+        HIP_TRY(hipMemsetAsync(ws.shards, 0, RT_WF_SHARDS * sizeof(WfShard), stream));
+        HIP_TRY(hipMemcpyAsync(const_cast<RtCameraDesc*>(ws.cam), cam, sizeof(RtCameraDesc), hipMemcpyHostToDevice, stream));
+        auto level = [&](auto primary, auto later, unsigned k) {
+            if (k == 0)
+                hipLaunchKernelGGL(primary, grid, block, lds, stream, scene->dev, *cam, (int)depth, rows, d_out, d_stats,
+                                   scene->d_status, ws, k);
+            else
+                hipLaunchKernelGGL(later, dim3(RT_WF_GRID), block, lds, stream, scene->dev, *cam, (int)depth, rows, d_out,
+                                   d_stats, scene->d_status, ws, k);
+        };
+#define RT_WF_PAIR(ST, FL, SG) wf_level_kernel<ST, FL, SG, true>, wf_level_kernel<ST, FL, SG, false>
+        for (unsigned k = 0; k <= depth; ++k) {
+            if (d_stats)
+                staged ? level(RT_WF_PAIR(true, true, true), k)
+                       : (flat ? level(RT_WF_PAIR(true, true, false), k) : level(RT_WF_PAIR(true, false, false), k));
+            else
+                staged ? level(RT_WF_PAIR(false, true, true), k)
+                       : (flat ? level(RT_WF_PAIR(false, true, false), k) : level(RT_WF_PAIR(false, false, false), k));
+            hipLaunchKernelGGL(wf_mark_kernel, dim3(1), dim3(RT_WF_SHARDS), 0, stream, ws, k);
+        }
+        for (unsigned k = depth; k-- > 0;)  // generation `depth` has no budget left and so no nodes
+            hipLaunchKernelGGL(wf_combine_kernel, dim3(RT_WF_GRID), block, 0, stream, ws, k, d_out);
+        HIP_TRY(hipGetLastError());
+        return RT_OK;
+    }
     auto go = [&](auto kernel) {
-        const unsigned lds = staged ? ((scene->dev.stage_bytes + 15u) & ~15u) + RT_LDS_LIST_BYTES : 0u;
         hipLaunchKernelGGL(kernel, grid, block, lds, stream, scene->dev, *cam, (int)depth,
                            rows, d_out, d_stats, scene->d_status);
     };
@@ -460,6 +686,12 @@ int rt_hip_scene_create(const RtSceneDesc* desc, RtScene** out) {
     s->d_status = nullptr;
     s->d_dev = nullptr;
     s->device = g_device;
+    std::memset(&s->wf, 0, sizeof s->wf);
+    s->wf_pixels = 0;
+    s->wf_mode = -1;
+    s->wf_q_items = s->wf_node_items = 0;
+    for (uint32_t k = 0; k < desc->n_materials; ++k)  // world.rs:99,110: these are the only tests that let color_at recurse
+        if (desc->materials[k].reflective != 0.0 || desc->materials[k].transparency != 0.0) flags |= RT_SCENE_RECURSIVE;
     int rc = RT_OK;
     auto up = [&](auto* src, size_t n, auto** dst) {
         if (rc != RT_OK) return;
@@ -556,7 +788,20 @@ int rt_hip_scene_create(const RtSceneDesc* desc, RtScene** out) {
 void rt_hip_scene_destroy(RtScene* scene) {
     if (!scene) return;
     for (void* p : scene->allocations) (void)hipFree(p);
+    for (void* p : {(void*)scene->wf.queue[0], (void*)scene->wf.queue[1], (void*)scene->wf.nodes, (void*)scene->wf.shards})
+        if (p) (void)hipFree(p);
     delete scene;
+}
+
+int rt_hip_scene_set_wavefront(RtScene* scene, int mode, uint64_t queue_items, uint64_t node_items) {
+    if (!scene || mode < -1 || mode > 1) return RT_ERR_INVALID_ARG;
+    if (queue_items >= 0x80000000ull || node_items >= 0x40000000ull) return RT_ERR_INVALID_ARG;
+    scene->wf_mode = mode;
+    if (scene->wf_q_items != queue_items || scene->wf_node_items != node_items) {
+        scene->wf_q_items = (size_t)queue_items, scene->wf_node_items = (size_t)node_items;
+        scene->wf_pixels = 0;  // the next launch re-sizes the workspace
+    }
+    return RT_OK;
 }
 
 int rt_hip_scene_status(const RtScene* scene, void* hip_stream) {

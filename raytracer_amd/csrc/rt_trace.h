@@ -38,6 +38,7 @@ namespace rtd {
 #define RT_CONTAINERS_CAP RT_LIST_CAP
 #define RT_SCENE_HAS_SHADOWLESS 1u
 #define RT_SCENE_FLAT 2u  // primitives only at world level, no acceleration structure
+#define RT_SCENE_RECURSIVE 4u  // some material reflects or transmits: color_at can recurse (world.rs:98-127)
 
 struct SceneDev {
     const RtShape* __restrict__ shapes;
@@ -143,29 +144,36 @@ RT_DEV void cswap(double& a, double& b) {
     a = lo;
     b = hi;
 }
+// N: the most entries the primitive kind can return (1 plane / triangle, 2 sphere / cube, 4 conic);
+// slots >= N are left alone and their keep bits stay clear.
+template <int N>
 RT_DEV void finish_hits(PrimHits& h, unsigned& status) {
     const double INF = __builtin_inf();
     // NaN distances: the reference panics (intersection.rs:119); drop and flag
     int m = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < N; ++i) {
         const bool valid = i < h.n && h.t[i] == h.t[i];
         if (i < h.n && !valid) status |= RT_STATUS_NAN_T;
         h.t[i] = valid ? h.t[i] : INF;
         m += valid ? 1 : 0;
     }
-    if (h.n > 1) {
+    if constexpr (N == 2) {
         cswap(h.t[0], h.t[1]);
-        cswap(h.t[2], h.t[3]);
-        cswap(h.t[0], h.t[2]);
-        cswap(h.t[1], h.t[3]);
-        cswap(h.t[1], h.t[2]);
+    } else if constexpr (N == 4) {
+        if (h.n > 1) {
+            cswap(h.t[0], h.t[1]);
+            cswap(h.t[2], h.t[3]);
+            cswap(h.t[0], h.t[2]);
+            cswap(h.t[1], h.t[3]);
+            cswap(h.t[1], h.t[2]);
+        }
     }
     h.n = m;
     unsigned keep = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const bool drop = (i + 1 < m) && t_eq(h.t[i], h.t[i + 1 < 4 ? i + 1 : 3]);
+    for (int i = 0; i < N; ++i) {
+        const bool drop = (i + 1 < N) && (i + 1 < m) && t_eq(h.t[i], h.t[i + 1 < N ? i + 1 : N - 1]);
         if (i < m && !drop) keep |= 1u << i;
     }
     h.keep = keep;
@@ -201,20 +209,24 @@ RT_DEV void prim_intersect_rec(const double* __restrict__ inv, unsigned kf, cons
     h.n = 0;
     if (kind == RT_SPHERE) {
         h.n = sphere_intersect(r, h.t);
+        finish_hits<2>(h, cx.status);
     } else if (kind == RT_PLANE) {
         h.n = plane_intersect(r, h.t);
+        finish_hits<1>(h, cx.status);
     } else if (kind == RT_CUBE) {
         h.n = cube_intersect(r, h.t);
+        finish_hits<2>(h, cx.status);
     } else if (kind == RT_CYLINDER || kind == RT_CONE) {
         const RtConic c = *conic;
         const bool closed = (kf & RT_FLAG_CLOSED) != 0;
         h.n = kind == RT_CYLINDER ? cylinder_intersect(r, c.minimum, c.maximum, closed, h.t)
                                   : cone_intersect(r, c.minimum, c.maximum, closed, h.t);
+        finish_hits<4>(h, cx.status);
     } else {
         double u, v;
         h.n = triangle_intersect(tri, r, h.t, u, v);
+        finish_hits<1>(h, cx.status);
     }
-    finish_hits(h, cx.status);
 }
 
 template <bool STATS, bool FLAT>
@@ -227,20 +239,24 @@ RT_DEV void prim_intersect(const SceneDev& S, const RtShape* __restrict__ sh, un
     h.n = 0;
     if (kind == RT_SPHERE) {
         h.n = sphere_intersect(r, h.t);
+        finish_hits<2>(h, cx.status);
     } else if (kind == RT_PLANE) {
         h.n = plane_intersect(r, h.t);
+        finish_hits<1>(h, cx.status);
     } else if (kind == RT_CUBE) {
         h.n = cube_intersect(r, h.t);
+        finish_hits<2>(h, cx.status);
     } else if (kind == RT_CYLINDER || kind == RT_CONE) {
         const RtConic c = S.conics[sh->param];
         const bool closed = (kf & RT_FLAG_CLOSED) != 0;
         h.n = kind == RT_CYLINDER ? cylinder_intersect(r, c.minimum, c.maximum, closed, h.t)
                                   : cone_intersect(r, c.minimum, c.maximum, closed, h.t);
+        finish_hits<4>(h, cx.status);
     } else {
         double u, v;
         h.n = triangle_intersect(S.tris + sh->param, r, h.t, u, v);
+        finish_hits<1>(h, cx.status);
     }
-    finish_hits(h, cx.status);
 }
 
 // ---- sorted hit list (stands for BTreeSet<Intersection>) -----------------------
@@ -982,6 +998,82 @@ RT_DEV bool find_hit(const SceneDev& S, SW& W, const Ray& ray, Best& best, Ctx<S
     return best.idx >= 0;
 }
 
+// ---- wave-front organisation of the recursion ---------------------------------------------
+// In scenes with reflective / transparent materials the lanes of a wave disagree about how deep
+// their recursion goes, and a wave that keeps every lane's whole ray tree to itself runs mostly
+// empty below the first bounce.  The level kernels instead trace ONE generation of colour rays
+// each: a shade_hit that needs child colours parks what it has in a WfNode, appends its
+// reflected / refracted rays to the next generation's queue (dense again, whatever pixels they
+// came from) and ends; combine kernels then fold the children's colours into their nodes from
+// the deepest generation upwards with the arithmetic of world.rs:76-82, in the same order.
+//
+// Slots are handed out with ONE 64-bit atomic per wave and generation step (the lanes that need
+// slots first finish their shade_hit, then ask together), on one of RT_WF_SHARDS counters chosen
+// by the wave's number: device-scope atomics on a single address serialise at ~0.1 us each.
+// Each shard owns a slice of the queue and of the node pool.  A request that does not fit is
+// refused and the hit keeps its subtree to itself (color_at's frame stack), so capacity only
+// ever costs speed, never the result.
+struct WfItem {  // one colour ray of the next generation
+    Ray ray;
+    uint32_t parent;     // RT_WF_PIXEL | framebuffer slot, or (node << 1) | child slot
+    uint32_t remaining;  // recursion budget of this ray; RT_WF_EMPTY: nothing here
+    uint32_t pad[2];
+};
+struct WfNode {  // a shade_hit waiting for its children (world.rs:72-82)
+    V3 surface;
+    V3 child[2];  // color_at of the reflected / refracted ray, as delivered
+    double reflective, transparency, reflectance;
+    uint32_t parent;
+    uint32_t flags;
+    double pad[3];
+};
+static_assert(sizeof(WfItem) == 64 && sizeof(WfNode) == 128, "wave-front records are sized for aligned per-lane stores");
+#define RT_WF_PIXEL 0x80000000u
+#define RT_WF_EMPTY 0xffffffffu
+enum { WF_USE_SCHLICK = 1u, WF_HAS_REFLECT = 2u, WF_HAS_REFRACT = 4u, WF_DEAD = 8u };
+#define RT_WF_LEVELS (RT_MAX_DEPTH + 2)
+#define RT_WF_SHARDS 256u
+struct WfShard {  // one cache line of counters
+    // asked of this shard while generation g was traced: nodes (low half), items of generation g + 1
+    // (high half); both may run past the capacity -- those requests were refused
+    unsigned long long asked[RT_WF_LEVELS];
+    unsigned node_begin[RT_WF_LEVELS + 1];  // generation g's nodes are [node_begin[g], node_begin[g + 1]) of the shard's slice
+    unsigned pad;
+};
+static_assert(sizeof(WfShard) == 128, "one shard per 128-byte line");
+struct WfSpace {
+    WfItem* queue[2];  // generation g reads queue[g & 1] and appends to queue[(g + 1) & 1]
+    WfNode* nodes;
+    WfShard* shards;
+    const RtCameraDesc* cam;   // the launch's camera record, for the rare lane that has to start over
+    unsigned q_cap, node_cap;  // per shard
+};
+
+RT_DEV unsigned wf_items_of(const WfSpace& ws, unsigned shard, unsigned level) {  // level >= 1
+    const unsigned n = (unsigned)(ws.shards[shard].asked[level - 1u] >> 32);
+    return n < ws.q_cap ? n : ws.q_cap;
+}
+
+RT_DEV void wf_deliver(WfNode* __restrict__ nodes, double* __restrict__ out, uint32_t parent, V3 value) {
+    if (parent & RT_WF_PIXEL) {
+        double* o = out + (size_t)(parent & ~RT_WF_PIXEL) * 3u;
+        o[0] = value.x, o[1] = value.y, o[2] = value.z;
+    } else {
+        nodes[parent >> 1].child[parent & 1u] = value;
+    }
+}
+
+struct NoSpill {  // the whole ray tree stays with the lane
+    static constexpr bool enabled = false;
+    RT_DEV bool operator()(V3, double, double, double, bool, bool, const Ray&, bool, const Ray&, int) { return false; }
+};
+// color_at's switch in the wave-front kernels: open, the lane's first shade_hit returns to the kernel
+// once it is lit; closed (a lane that found no room before), color_at keeps the subtree.
+struct WfPending {
+    static constexpr bool enabled = true;
+    bool open;
+};
+
 // The hit being lit: what shade_hit keeps while its shadow feelers are traced.  (Kept in
 // registers on purpose: parking it in the private frame stack cost 20-30 % on small scenes.)
 struct Shade {
@@ -992,15 +1084,105 @@ struct Shade {
     int want_n;
 };
 
+// reflected_color / refracted_color's decisions for a lit hit (world.rs:98-127, intersection.rs:182-200)
+struct Children {
+    bool do_reflect, do_refract, use_schlick;
+    Ray refract_ray;
+    double reflectance;
+};
+template <bool STATS, bool FLAT>
+RT_DEV void shade_children(const RtMaterial& m, const Shade& sd, const Ray& ray, int remaining, Children& ch,
+                           Ctx<STATS, FLAT>& cx) {
+    ch.do_reflect = !(m.reflective == 0.0 || remaining == 0);
+    ch.do_refract = false;
+    ch.refract_ray = ray;
+    if (sd.want_n != 0) {
+        const double n_ratio = sd.n1 / sd.n2;
+        const double cos_i = dot(sd.eye, sd.normal);
+        const double sin2_t = (n_ratio * n_ratio) * (1.0 - cos_i * cos_i);
+        if (!(sin2_t > 1.0)) {
+            const double cos_t = sqrt(1.0 - sin2_t);
+            ch.do_refract = true;
+            ch.refract_ray.o = sd.under;
+            ch.refract_ray.d = sd.normal * (n_ratio * cos_i - cos_t) - sd.eye * n_ratio;
+        }
+    }
+    ch.use_schlick = m.reflective > 0.0 && m.transparency > 0.0;
+    ch.reflectance = 0.0;
+    if (ch.use_schlick && remaining != 0) {
+        count(cx, ST_SCHLICK);
+        Comps c;
+        c.eye_v = sd.eye, c.normal_v = sd.normal, c.n1 = sd.n1, c.n2 = sd.n2;
+        ch.reflectance = schlick(c);
+    }
+}
+
+// Called by every lane still in the kernel's item loop; `want`: this lane has children to place.
+// Returns false for a lane whose request found no room.
+RT_DEV bool wf_commit(const WfSpace& ws, unsigned shard, unsigned level, bool want, uint32_t parent, V3 surface,
+                      double reflective, double transparency, const Children& ch, V3 reflect_o, V3 reflect_d,
+                      int remaining_children) {
+    const unsigned long long asking = __builtin_amdgcn_ballot_w64(want);
+    if (asking == 0ull) return false;
+    const bool both = want && ch.do_reflect && ch.do_refract;
+    const unsigned long long two = __builtin_amdgcn_ballot_w64(both);
+    const unsigned lane = __lane_id();
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const unsigned n_nodes = (unsigned)__builtin_popcountll(asking);
+    const unsigned n_items = n_nodes + (unsigned)__builtin_popcountll(two);
+    const int leader = __builtin_ctzll(__builtin_amdgcn_ballot_w64(true));
+    unsigned long long base = 0ull;
+    if ((int)lane == leader)
+        base = atomicAdd(&ws.shards[shard].asked[level], ((unsigned long long)n_items << 32) | n_nodes);
+    const unsigned base_nodes = (unsigned)__shfl((int)(unsigned)(base & 0xffffffffull), leader, 64);
+    const unsigned base_items = (unsigned)__shfl((int)(unsigned)(base >> 32), leader, 64);
+    if (!want) return false;
+    // (a count past 2^32 would carry into the other half: with < 2^29 pixels, <= 63 colour rays per
+    // pixel and 256 shards a shard is asked for fewer than 2^28 nodes)
+    const unsigned rank = (unsigned)__builtin_popcountll(asking & below);
+    const unsigned kids = both ? 2u : 1u;
+    const unsigned long long ni = (unsigned long long)ws.shards[shard].node_begin[level] + base_nodes + rank;
+    const unsigned long long qi = (unsigned long long)base_items + rank + (unsigned)__builtin_popcountll(two & below);
+    WfItem* __restrict__ q = ws.queue[(level + 1u) & 1u] + (size_t)shard * ws.q_cap;
+    WfNode* __restrict__ nodes = ws.nodes + (size_t)shard * ws.node_cap;
+    if (!(ni < ws.node_cap && qi + kids <= ws.q_cap)) {
+        // no room: blank whatever part of the request did fit
+        if (ni < ws.node_cap) nodes[ni].flags = WF_DEAD;
+        for (unsigned k = 0; k < kids; ++k)
+            if (qi + k < ws.q_cap) q[qi + k].remaining = RT_WF_EMPTY;
+        return false;
+    }
+    WfNode& n = nodes[ni];
+    n.surface = surface;
+    n.child[0] = v3(0.0, 0.0, 0.0);
+    n.child[1] = v3(0.0, 0.0, 0.0);
+    n.reflective = reflective, n.transparency = transparency, n.reflectance = ch.reflectance;
+    n.parent = parent;
+    n.flags = (ch.use_schlick ? WF_USE_SCHLICK : 0u) | (ch.do_reflect ? WF_HAS_REFLECT : 0u) | (ch.do_refract ? WF_HAS_REFRACT : 0u);
+    const uint32_t global_node = (uint32_t)((size_t)shard * ws.node_cap + ni);
+    unsigned at = (unsigned)qi;
+    if (ch.do_reflect) {
+        WfItem& it = q[at++];
+        it.ray = Ray{reflect_o, reflect_d}, it.parent = global_node << 1, it.remaining = (uint32_t)remaining_children;
+    }
+    if (ch.do_refract) {
+        WfItem& it = q[at];
+        it.ray = ch.refract_ray, it.parent = (global_node << 1) | 1u, it.remaining = (uint32_t)remaining_children;
+    }
+    return true;
+}
+
 // One loop iteration traces ONE ray per lane -- a colour ray (primary, reflected, refracted) or
 // a shadow feeler -- and then advances that lane's shade_hit state machine; the wave never
 // splits into "lanes tracing shadows" and "lanes tracing colour rays".
-template <bool STATS, bool FLAT, class SW>
-RT_DEV V3 color_at(const SceneDev& S, SW& W, Frame* frames, Ray ray, int remaining, Ctx<STATS, FLAT>& cx) {
+// `spill` (wave-front kernels): offered the children of the lane's FIRST shade_hit; when it takes
+// them, `deferred` is set and the returned colour means nothing.
+template <bool STATS, bool FLAT, class SW, class SP>
+RT_DEV V3 color_at(const SceneDev& S, SW& W, Frame* frames, Ray ray, int remaining, Ctx<STATS, FLAT>& cx, SP& spill,
+                   bool& deferred, Shade& sd) {
     int sp = 0;
     bool shadow = false;
     double limit = 0.0;
-    Shade sd;
     sd.li = 0u;
     sd.mat = 0;
     sd.want_n = 0;
@@ -1093,29 +1275,20 @@ RT_DEV V3 color_at(const SceneDev& S, SW& W, Frame* frames, Ray ray, int remaini
         }
         if (retrace) continue;
         if (!have_value) {  // all lights in: reflected_color / refracted_color (world.rs:72-82,98-127)
-            const RtMaterial m = S.mats[sd.mat];
-            const bool do_reflect = !(m.reflective == 0.0 || remaining == 0);
-            bool do_refract = false;
-            Ray refract_ray = ray;
-            if (sd.want_n != 0) {
-                const double n_ratio = sd.n1 / sd.n2;
-                const double cos_i = dot(sd.eye, sd.normal);
-                const double sin2_t = (n_ratio * n_ratio) * (1.0 - cos_i * cos_i);
-                if (!(sin2_t > 1.0)) {
-                    const double cos_t = sqrt(1.0 - sin2_t);
-                    do_refract = true;
-                    refract_ray.o = sd.under;
-                    refract_ray.d = sd.normal * (n_ratio * cos_i - cos_t) - sd.eye * n_ratio;
+            if constexpr (SP::enabled) {
+                // wave-front kernels: the lane's first shade_hit ends here; its children are worked out
+                // from `sd` by the kernel once the whole wave is through (nothing else has to stay live)
+                if (sp == 0 && spill.open) {
+                    deferred = true;
+                    return v3(0.0, 0.0, 0.0);
                 }
             }
-            const bool use_schlick = m.reflective > 0.0 && m.transparency > 0.0;
-            double reflectance = 0.0;
-            if (use_schlick && remaining != 0) {
-                count(cx, ST_SCHLICK);
-                Comps c;
-                c.eye_v = sd.eye, c.normal_v = sd.normal, c.n1 = sd.n1, c.n2 = sd.n2;
-                reflectance = schlick(c);
-            }
+            const RtMaterial m = S.mats[sd.mat];
+            Children ch;
+            shade_children(m, sd, ray, remaining, ch, cx);
+            const bool do_reflect = ch.do_reflect, do_refract = ch.do_refract, use_schlick = ch.use_schlick;
+            const Ray refract_ray = ch.refract_ray;
+            const double reflectance = ch.reflectance;
             if (do_reflect || do_refract) {
                 Frame& f = frames[sp];
                 f.surface = sd.surface;
@@ -1165,6 +1338,14 @@ RT_DEV V3 color_at(const SceneDev& S, SW& W, Frame* frames, Ray ray, int remaini
             ++remaining;
         }
     }
+}
+
+template <bool STATS, bool FLAT, class SW>
+RT_DEV V3 color_at(const SceneDev& S, SW& W, Frame* frames, Ray ray, int remaining, Ctx<STATS, FLAT>& cx) {
+    NoSpill none;
+    bool deferred = false;
+    Shade sd;
+    return color_at(S, W, frames, ray, remaining, cx, none, deferred, sd);
 }
 
 // Camera::ray_for_pixel (camera.rs:68-80)

@@ -149,3 +149,43 @@ def test_conic_parallel_ray_branch_under_acceleration():
     # the branch really fires in this bundle: some hits lie outside the shape's y-range
     col = world.color_at(rays, 2)
     assert not rel_mismatch(col, ow.color_at(rays, 2)).any()
+
+
+def _render_resident(scene, cam, mode, queue_items=0, node_items=0, with_stats=False):
+    import ctypes as C
+    import torch
+    from raytracer_amd import _native as N
+    scene.set_wavefront(mode, queue_items, node_items)
+    H, W = cam.v_size, cam.h_size
+    out = torch.full((H, W, 3), -7.0, dtype=torch.float64, device="cuda")
+    d_stats = torch.zeros(256, dtype=torch.uint8, device="cuda") if with_stats else None
+    scene.render_rows(cam.desc(), 5, 0, 1, H, H, out.data_ptr(), None, d_stats.data_ptr() if with_stats else None)
+    torch.cuda.synchronize()
+    scene.status()
+    img = out.cpu().numpy()
+    if not with_stats:
+        return img
+    st = N.RtStats.from_buffer_copy(bytes(d_stats.cpu().numpy()[:C.sizeof(N.RtStats)])).as_dict()
+    return img, st
+
+
+@pytest.mark.parametrize("name,width,height", [("glass_bubble", 320, 180), ("cover", 320, 180), ("room", 256, 144),
+                                                ("csg", 200, 112), ("synthetic", 256, 144)])
+def test_generation_per_launch_equals_one_launch(name, width, height):
+    """color_at's recursion traced one generation of rays per launch (node pool + ray queues) gives the
+    frame of the one-launch kernel bit for bit and traces the same rays -- also when the queue or the
+    node pool is far too small and most hits have to keep their subtrees to themselves."""
+    world, cam = rt.synthetic(width, height, 1500) if name == "synthetic" else rt.exercise(name, width, height)
+    scene = rt.DeviceScene(world.flatten())
+    mono, st_mono = _render_resident(scene, cam, 0, with_stats=True)
+    wave, st_wave = _render_resident(scene, cam, 1, with_stats=True)
+    assert np.array_equal(mono, wave)
+    for key in ("rays_primary", "rays_shadow", "rays_reflect", "rays_refract", "hits_shaded", "container_passes"):
+        assert st_mono[key] == st_wave[key], key
+    assert st_mono["rays_reflect"] + st_mono["rays_refract"] > 0
+    pixels = width * height
+    for q_items, n_items in ((pixels // 7, pixels), (pixels, pixels // 11), (193, 61)):
+        assert np.array_equal(mono, _render_resident(scene, cam, 1, q_items, n_items))
+    assert np.array_equal(mono, _render_resident(scene, cam, -1))
+    ref, _ = orc.OracleWorld(world.describe()).render(cam)
+    compare(f"{name}-generations", wave, ref)
