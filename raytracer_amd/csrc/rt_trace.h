@@ -202,27 +202,33 @@ template <bool STATS, bool FLAT>
 RT_DEV void prim_intersect_rec(const double* __restrict__ inv, unsigned kf, const RtConic* __restrict__ conic,
                                const RtTriangle* __restrict__ tri, const Ray& parent_ray, PrimHits& h,
                                Ctx<STATS, FLAT>& cx) {
-    const Ray r = transform_ray(inv, parent_ray);  // shape.rs:28-32
+    // shape.rs:28-32, inside every branch (the kind is the same for the whole wave here): a kind that
+    // reads only part of the local ray -- a plane: its y components -- pays only for that part
     const unsigned kind = RT_KIND(kf);
     count(cx, ST_RAY_XFORM);
     count(cx, ST_PRIM0 + (int)kind);
     h.n = 0;
     if (kind == RT_SPHERE) {
+        const Ray r = transform_ray(inv, parent_ray);
         h.n = sphere_intersect(r, h.t);
         finish_hits<2>(h, cx.status);
     } else if (kind == RT_PLANE) {
+        const Ray r = transform_ray(inv, parent_ray);
         h.n = plane_intersect(r, h.t);
         finish_hits<1>(h, cx.status);
     } else if (kind == RT_CUBE) {
+        const Ray r = transform_ray(inv, parent_ray);
         h.n = cube_intersect(r, h.t);
         finish_hits<2>(h, cx.status);
     } else if (kind == RT_CYLINDER || kind == RT_CONE) {
+        const Ray r = transform_ray(inv, parent_ray);
         const RtConic c = *conic;
         const bool closed = (kf & RT_FLAG_CLOSED) != 0;
         h.n = kind == RT_CYLINDER ? cylinder_intersect(r, c.minimum, c.maximum, closed, h.t)
                                   : cone_intersect(r, c.minimum, c.maximum, closed, h.t);
         finish_hits<4>(h, cx.status);
     } else {
+        const Ray r = transform_ray(inv, parent_ray);
         double u, v;
         h.n = triangle_intersect(tri, r, h.t, u, v);
         finish_hits<1>(h, cx.status);
@@ -232,7 +238,8 @@ RT_DEV void prim_intersect_rec(const double* __restrict__ inv, unsigned kf, cons
 template <bool STATS, bool FLAT>
 RT_DEV void prim_intersect(const SceneDev& S, const RtShape* __restrict__ sh, unsigned kf, const Ray& parent_ray,
                            PrimHits& h, Ctx<STATS, FLAT>& cx) {
-    const Ray r = transform_ray(sh->inv, parent_ray);  // shape.rs:28-32
+    // shape.rs:28-32, ahead of the branches: lanes holding different kinds of primitive share it
+    const Ray r = transform_ray(sh->inv, parent_ray);
     const unsigned kind = RT_KIND(kf);
     count(cx, ST_RAY_XFORM);
     count(cx, ST_PRIM0 + (int)kind);
