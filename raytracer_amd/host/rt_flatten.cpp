@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <thread>
 #include <cstring>
 #include <map>
 #include <string>
@@ -29,16 +30,16 @@ struct ABox {
         const double c[3] = {p.x, p.y, p.z};
         for (int a = 0; a < 3; ++a) {
             if (!std::isfinite(c[a])) unbounded = true;
-            mn[a] = std::fmin(mn[a], c[a]);
-            mx[a] = std::fmax(mx[a], c[a]);
+            mn[a] = c[a] < mn[a] ? c[a] : mn[a];  // (comparisons, not fmin/fmax: those are libm calls; a NaN is caught above)
+            mx[a] = c[a] > mx[a] ? c[a] : mx[a];
         }
     }
     void merge(const ABox& o) {
         if (o.unbounded) unbounded = true;
         if (o.empty()) return;
         for (int a = 0; a < 3; ++a) {
-            mn[a] = std::fmin(mn[a], o.mn[a]);
-            mx[a] = std::fmax(mx[a], o.mx[a]);
+            mn[a] = o.mn[a] < mn[a] ? o.mn[a] : mn[a];
+            mx[a] = o.mx[a] > mx[a] ? o.mx[a] : mx[a];
         }
     }
     ABox transformed(const Matrix4& t) const {
@@ -116,7 +117,8 @@ void build_bvh_range(std::vector<BvhItem>& items, size_t lo, size_t hi, int32_t 
     }
     node.shape = -1;
     // choose the split
-    int best_axis = 0;
+    int best_axis = -1, best_bin = 0;
+    double best_c0 = 0.0, best_scale = 0.0;
     size_t best_mid = lo + n / 2;
     double best_cost = INFINITY;
     constexpr int kBins = 16;
@@ -153,19 +155,24 @@ void build_bvh_range(std::vector<BvhItem>& items, size_t lo, size_t hi, int32_t 
             if (cost < best_cost) {
                 best_cost = cost;
                 best_axis = a;
+                best_bin = b;  // bins [0, b] go left
+                best_c0 = c0, best_scale = scale;
                 best_mid = lo + cnt;
-                // remember the plane through the bin boundary
             }
         }
     }
-    // partition by centroid order along the chosen axis (nth_element keeps it deterministic enough:
-    // ties broken by shape index)
-    auto less = [best_axis](const BvhItem& x, const BvhItem& y) {
-        const double cx = x.box.centroid(best_axis), cy = y.box.centroid(best_axis);
-        return cx < cy || (cx == cy && x.shape < y.shape);
-    };
-    std::sort(items.begin() + static_cast<long>(lo), items.begin() + static_cast<long>(hi), less);
-    if (best_mid <= lo || best_mid >= hi) best_mid = lo + n / 2;
+    const auto first = items.begin() + static_cast<long>(lo), last = items.begin() + static_cast<long>(hi);
+    if (best_axis >= 0 && best_mid > lo && best_mid < hi) {
+        // the items of bins [0, best_bin] to the left, order kept: linear, and the same tree whatever the input order
+        std::stable_partition(first, last, [&](const BvhItem& x) {
+            int b = static_cast<int>((x.box.centroid(best_axis) - best_c0) * best_scale);
+            b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+            return b <= best_bin;
+        });
+    } else {  // every centroid in one spot: halve by shape index
+        std::sort(first, last, [](const BvhItem& x, const BvhItem& y) { return x.shape < y.shape; });
+        best_mid = lo + n / 2;
+    }
     const size_t self = nodes.size();
     nodes.push_back(node);
     const size_t n_left = best_mid - lo;
@@ -475,20 +482,41 @@ void build_direction_index(FlatScene& f, uint32_t res) {
         f.dir_cands.push_back(c);
     }
     if (f.dir_cands.empty()) return;
-    std::vector<std::pair<uint32_t, uint32_t>> pairs;
-    for (uint32_t k = 0; k < f.dir_cands.size(); ++k) {
-        const RtDirCand& c = f.dir_cands[k];
-        const double qnorm = (c.thr - 1e-4 * (1.0 + 1e-5)) / 1e-9;
-        for (int face = 0; face < 6; ++face) raster_cand(c, qnorm, k, res, face, 0, 0, res, pairs);
+    // candidates are rasterised independently: blocks of them on host threads, merged in candidate order
+    // so that the table does not depend on the number of threads
+    unsigned n_threads = std::thread::hardware_concurrency();
+    n_threads = n_threads == 0 ? 1 : (n_threads > 16 ? 16 : n_threads);
+    if (f.dir_cands.size() < 64) n_threads = 1;
+    std::vector<std::vector<std::pair<uint32_t, uint32_t>>> part(n_threads);
+    auto work = [&](unsigned t) {
+        const size_t k0 = f.dir_cands.size() * t / n_threads, k1 = f.dir_cands.size() * (t + 1) / n_threads;
+        for (size_t k = k0; k < k1; ++k) {
+            const RtDirCand& c = f.dir_cands[k];
+            const double qnorm = (c.thr - 1e-4 * (1.0 + 1e-5)) / 1e-9;
+            for (int face = 0; face < 6; ++face)
+                raster_cand(c, qnorm, static_cast<uint32_t>(k), res, face, 0, 0, res, part[t]);
+        }
+    };
+    if (n_threads == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < n_threads; ++t) pool.emplace_back(work, t);
+        for (std::thread& th : pool) th.join();
     }
     const size_t n_cells = static_cast<size_t>(6) * res * res;
     f.dir_res = res;
     f.dir_cell_start.assign(n_cells + 1, 0);
-    for (const auto& pr : pairs) ++f.dir_cell_start[pr.first + 1];
+    size_t n_pairs = 0;
+    for (const auto& pairs : part) {
+        n_pairs += pairs.size();
+        for (const auto& pr : pairs) ++f.dir_cell_start[pr.first + 1];
+    }
     for (size_t c = 0; c < n_cells; ++c) f.dir_cell_start[c + 1] += f.dir_cell_start[c];
-    f.dir_entries.resize(pairs.size());
+    f.dir_entries.resize(n_pairs);
     std::vector<uint32_t> fill(f.dir_cell_start.begin(), f.dir_cell_start.end() - 1);
-    for (const auto& pr : pairs) f.dir_entries[fill[pr.first]++] = pr.second;
+    for (const auto& pairs : part)
+        for (const auto& pr : pairs) f.dir_entries[fill[pr.first]++] = pr.second;
 }
 
 }  // namespace
