@@ -77,6 +77,9 @@ def main():
     scene = rt.DeviceScene(flat)
     fd = flat.desc.contents
     scene_is_flat = fd.world_bvh_root < 0 and all((fd.shapes[i].kind_flags & 0xff) <= 6 for i in range(fd.n_shapes))
+    # the library's default policy (rt_hip.hip launch_render): large scenes that can recurse run one launch per generation of rays
+    recursive = any(fd.materials[i].reflective != 0.0 or fd.materials[i].transparency != 0.0 for i in range(fd.n_materials))
+    generations = recursive and not scene_is_flat and fd.n_shapes >= 1024 and args.depth > 0
     cd = cam.desc()
     band = tiling.DEFAULT_BAND_ROWS
     n_parts = world_size
@@ -174,7 +177,8 @@ def main():
             },
             "roofline": {
                 "bound": "valu_f64",
-                "kernel": "render_kernel<STATS=false, FLAT=%s>" % ("true" if scene_is_flat else "false"),
+                "kernel": ("wf_level_kernel<STATS=false, FLAT=false> x %d generations + wf_combine_kernel" % (args.depth + 1))
+                if generations else "render_kernel<STATS=false, FLAT=%s>" % ("true" if scene_is_flat else "false"),
                 "achieved": round(achieved, 4),
                 "peak": flops.PEAK_FP64_VALU_TFLOPS,
                 "unit": "TFLOP/s",
