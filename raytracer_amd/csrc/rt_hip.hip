@@ -61,8 +61,18 @@ __device__ void flush_stats(Ctx<STATS, FLAT>& cx, RtStats* __restrict__ stats, u
 // prepare_computations / lighting / pattern evaluation then cost an LDS access, not an L2 one.
 extern __shared__ __align__(16) unsigned char rt_lds[];
 
-template <bool STATS, bool FLAT, bool STAGED>
-__global__ __launch_bounds__(256, FLAT ? RT_WAVES_PER_SIMD_FLAT : RT_WAVES_PER_SIMD) void render_kernel(const SceneDev S_in, RtCameraDesc cam, int depth, RowMap rows,
+#ifndef RT_WAVES_PER_SIMD_OPAQUE
+#define RT_WAVES_PER_SIMD_OPAQUE 3  // FLAT scenes; measured 2 / 3 / 4: pattern.rs 0.97 / 0.83 / 1.02 ms (profiles/r01_variants.txt)
+#endif
+#ifndef RT_WAVES_PER_SIMD_OPAQUE_GENERAL
+#define RT_WAVES_PER_SIMD_OPAQUE_GENERAL 2
+#endif
+// RECURSE == false: no material of the scene reflects or transmits (world.rs:99,110 always take their
+// early exits), so the kernel is instantiated with a recursion budget of zero: no frames, no n1 / n2,
+// and under_point / reflect_v / the containers walk fall away as dead code.
+template <bool STATS, bool FLAT, bool STAGED, bool RECURSE = true>
+__global__ __launch_bounds__(256, !RECURSE ? (FLAT ? RT_WAVES_PER_SIMD_OPAQUE : RT_WAVES_PER_SIMD_OPAQUE_GENERAL)
+                                           : (FLAT ? RT_WAVES_PER_SIMD_FLAT : RT_WAVES_PER_SIMD)) void render_kernel(const SceneDev S_in, RtCameraDesc cam, int depth, RowMap rows,
                                                      double* __restrict__ out, RtStats* __restrict__ stats,
                                                      unsigned* __restrict__ status) {
     SceneDev S = S_in;
@@ -100,7 +110,7 @@ __global__ __launch_bounds__(256, FLAT ? RT_WAVES_PER_SIMD_FLAT : RT_WAVES_PER_S
         Frame frames[RT_MAX_DEPTH + 1];
         const Ray ray = ray_for_pixel(cam, x, y);
         count(cx, ST_RAY_PRIMARY);
-        const V3 c = color_at(S, W, frames, ray, depth, cx);
+        const V3 c = color_at(S, W, frames, ray, RECURSE ? depth : 0, cx);
         double* o = out + ((size_t)k * cam.hsize + x) * 3u;
         o[0] = c.x;
         o[1] = c.y;
@@ -573,7 +583,11 @@ int launch_render(const RtScene* scene, const RtCameraDesc* cam, uint32_t depth,
     if (grid.y > 65535u * 16u) return RT_ERR_INVALID_ARG;
     const bool flat = (scene->dev.flags & RT_SCENE_FLAT) != 0;
     const bool staged = flat && scene->dev.stage_bytes != 0;
-    const unsigned lds = staged ? ((scene->dev.stage_bytes + 15u) & ~15u) + RT_LDS_LIST_BYTES : 0u;
+    // the per-lane list area is read only by the containers walk and by shadow tests among shadowless
+    // primitives: a scene with neither leaves the LDS to more resident blocks
+    const bool opaque_scene = (scene->dev.flags & RT_SCENE_RECURSIVE) == 0;
+    const bool needs_list = !opaque_scene || (scene->dev.flags & RT_SCENE_HAS_SHADOWLESS) != 0;
+    const unsigned lds = staged ? ((scene->dev.stage_bytes + 15u) & ~15u) + (needs_list ? RT_LDS_LIST_BYTES : 0u) : 0u;
     // Large scenes whose materials can spawn reflected / refracted rays are traced one generation of rays per
     // launch (dense waves at every depth); the others in one launch, each lane keeping its pixel.  The
     // generations cost ~400 B of queue and node traffic per colour ray, which only pays where a ray is
@@ -616,12 +630,21 @@ int launch_render(const RtScene* scene, const RtCameraDesc* cam, uint32_t depth,
         hipLaunchKernelGGL(kernel, grid, block, lds, stream, scene->dev, *cam, (int)depth,
                            rows, d_out, d_stats, scene->d_status);
     };
-    if (d_stats)
+    const bool opaque = (scene->dev.flags & RT_SCENE_RECURSIVE) == 0;
+    if (opaque) {
+        if (d_stats)
+            staged ? go(render_kernel<true, true, true, false>)
+                   : (flat ? go(render_kernel<true, true, false, false>) : go(render_kernel<true, false, false, false>));
+        else
+            staged ? go(render_kernel<false, true, true, false>)
+                   : (flat ? go(render_kernel<false, true, false, false>) : go(render_kernel<false, false, false, false>));
+    } else if (d_stats) {
         staged ? go(render_kernel<true, true, true>)
                : (flat ? go(render_kernel<true, true, false>) : go(render_kernel<true, false, false>));
-    else
+    } else {
         staged ? go(render_kernel<false, true, true>)
                : (flat ? go(render_kernel<false, true, false>) : go(render_kernel<false, false, false>));
+    }
     HIP_TRY(hipGetLastError());
     return RT_OK;
 }
