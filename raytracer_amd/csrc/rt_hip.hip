@@ -61,18 +61,14 @@ __device__ void flush_stats(Ctx<STATS, FLAT>& cx, RtStats* __restrict__ stats, u
 // prepare_computations / lighting / pattern evaluation then cost an LDS access, not an L2 one.
 extern __shared__ __align__(16) unsigned char rt_lds[];
 
-#ifndef RT_WAVES_PER_SIMD_OPAQUE
-#define RT_WAVES_PER_SIMD_OPAQUE 3  // FLAT scenes; measured 2 / 3 / 4: pattern.rs 0.97 / 0.83 / 1.02 ms (profiles/r01_variants.txt)
-#endif
-#ifndef RT_WAVES_PER_SIMD_OPAQUE_GENERAL
-#define RT_WAVES_PER_SIMD_OPAQUE_GENERAL 2
-#endif
 // RECURSE == false: no material of the scene reflects or transmits (world.rs:99,110 always take their
 // early exits), so the kernel is instantiated with a recursion budget of zero: no frames, no n1 / n2,
 // and under_point / reflect_v / the containers walk fall away as dead code.
-template <bool STATS, bool FLAT, bool STAGED, bool RECURSE = true>
-__global__ __launch_bounds__(256, !RECURSE ? (FLAT ? RT_WAVES_PER_SIMD_OPAQUE : RT_WAVES_PER_SIMD_OPAQUE_GENERAL)
-                                           : (FLAT ? RT_WAVES_PER_SIMD_FLAT : RT_WAVES_PER_SIMD)) void render_kernel(const SceneDev S_in, RtCameraDesc cam, int depth, RowMap rows,
+// DENSE: 3 waves/SIMD (168 VGPRs, a few spilled) instead of 2 -- FLAT scenes whose LDS share lets three
+// blocks live on a CU.  Measured on pattern.rs (no recursion) at 2 / 3 / 4 waves/SIMD: 0.97 / 0.83 /
+// 1.02 ms; glass_bubble.rs 4.83 / 4.50 / -; the general kernel gains nothing (profiles/r01_variants.txt).
+template <bool STATS, bool FLAT, bool STAGED, bool RECURSE = true, bool DENSE = false>
+__global__ __launch_bounds__(256, DENSE ? 3 : (FLAT ? RT_WAVES_PER_SIMD_FLAT : RT_WAVES_PER_SIMD)) void render_kernel(const SceneDev S_in, RtCameraDesc cam, int depth, RowMap rows,
                                                      double* __restrict__ out, RtStats* __restrict__ stats,
                                                      unsigned* __restrict__ status) {
     SceneDev S = S_in;
@@ -106,7 +102,7 @@ __global__ __launch_bounds__(256, !RECURSE ? (FLAT ? RT_WAVES_PER_SIMD_OPAQUE : 
     if (active) {
         // STAGED scenes are small enough for the per-lane sorted list to live in LDS too
         typename std::conditional<STAGED, ScratchLds, Scratch>::type W;
-        if constexpr (STAGED) W.attach(rt_lds + ((S_in.stage_bytes + 15u) & ~15u), threadIdx.x);
+        if constexpr (STAGED) W.attach(rt_lds + ((S_in.stage_bytes + 15u) & ~15u), threadIdx.x, S_in.lds_list_cap);
         Frame frames[RT_MAX_DEPTH + 1];
         const Ray ray = ray_for_pixel(cam, x, y);
         count(cx, ST_RAY_PRIMARY);
@@ -148,7 +144,7 @@ __global__ __launch_bounds__(256, FLAT ? RT_WAVES_PER_SIMD_FLAT : RT_WAVES_PER_S
         for (int i = 0; i < ST_COUNT; ++i) cx.cnt[i] = 0;
     }
     typename std::conditional<STAGED, ScratchLds, Scratch>::type W;
-    if constexpr (STAGED) W.attach(rt_lds + ((S_in.stage_bytes + 15u) & ~15u), threadIdx.x);
+    if constexpr (STAGED) W.attach(rt_lds + ((S_in.stage_bytes + 15u) & ~15u), threadIdx.x, S_in.lds_list_cap);
     Frame frames[RT_MAX_DEPTH + 1];
     const unsigned out_shard = ((blockIdx.y * gridDim.x + blockIdx.x) * 4u + (threadIdx.x >> 6)) % RT_WF_SHARDS;  // per wave
     // One pass of one item: color_at up to the end of the lane's first shade_hit, then -- the wave
@@ -587,7 +583,7 @@ int launch_render(const RtScene* scene, const RtCameraDesc* cam, uint32_t depth,
     // primitives: a scene with neither leaves the LDS to more resident blocks
     const bool opaque_scene = (scene->dev.flags & RT_SCENE_RECURSIVE) == 0;
     const bool needs_list = !opaque_scene || (scene->dev.flags & RT_SCENE_HAS_SHADOWLESS) != 0;
-    const unsigned lds = staged ? ((scene->dev.stage_bytes + 15u) & ~15u) + (needs_list ? RT_LDS_LIST_BYTES : 0u) : 0u;
+    const unsigned lds = staged ? ((scene->dev.stage_bytes + 15u) & ~15u) + (needs_list ? RT_LDS_LIST_BYTES(scene->dev.lds_list_cap) : 0u) : 0u;
     // Large scenes whose materials can spawn reflected / refracted rays are traced one generation of rays per
     // launch (dense waves at every depth); the others in one launch, each lane keeping its pixel.  The
     // generations cost ~400 B of queue and node traffic per colour ray, which only pays where a ray is
@@ -631,20 +627,22 @@ int launch_render(const RtScene* scene, const RtCameraDesc* cam, uint32_t depth,
                            rows, d_out, d_stats, scene->d_status);
     };
     const bool opaque = (scene->dev.flags & RT_SCENE_RECURSIVE) == 0;
-    if (opaque) {
-        if (d_stats)
-            staged ? go(render_kernel<true, true, true, false>)
-                   : (flat ? go(render_kernel<true, true, false, false>) : go(render_kernel<true, false, false, false>));
-        else
-            staged ? go(render_kernel<false, true, true, false>)
-                   : (flat ? go(render_kernel<false, true, false, false>) : go(render_kernel<false, false, false, false>));
-    } else if (d_stats) {
-        staged ? go(render_kernel<true, true, true>)
-               : (flat ? go(render_kernel<true, true, false>) : go(render_kernel<true, false, false>));
-    } else {
-        staged ? go(render_kernel<false, true, true>)
-               : (flat ? go(render_kernel<false, true, false>) : go(render_kernel<false, false, false>));
-    }
+    // three blocks per CU need <= 160 KB / 3 of LDS each (and, unstaged, nothing says the denser variant pays)
+    const bool dense = staged && lds <= 53u * 1024u;
+    auto pick = [&](auto stats_tag) {
+        constexpr bool ST = decltype(stats_tag)::value;
+        if (!flat) return opaque ? go(render_kernel<ST, false, false, false>) : go(render_kernel<ST, false, false, true>);
+        if (!staged) return opaque ? go(render_kernel<ST, true, false, false>) : go(render_kernel<ST, true, false, true>);
+        if (opaque) return dense ? go(render_kernel<ST, true, true, false, true>) : go(render_kernel<ST, true, true, false>);
+#ifndef RT_DENSE_RECURSIVE
+#define RT_DENSE_RECURSIVE 1
+#endif
+        return dense && RT_DENSE_RECURSIVE ? go(render_kernel<ST, true, true, true, true>) : go(render_kernel<ST, true, true, true>);
+    };
+    if (d_stats)
+        pick(std::true_type{});
+    else
+        pick(std::false_type{});
     HIP_TRY(hipGetLastError());
     return RT_OK;
 }
@@ -783,6 +781,7 @@ int rt_hip_scene_create(const RtSceneDesc* desc, RtScene** out) {
         uint64_t world_hits = 0;  // most entries World::intersections can return: the per-lane list must hold them
         for (uint32_t i = 0; i < desc->n_shapes; ++i) world_hits += max_hits_of_kind(RT_KIND(desc->shapes[i].kind_flags));
         if (!image.empty() && image.size() <= RT_STAGE_MAX_BYTES && world_hits <= RT_LDS_LIST_CAP) {
+            s->dev.lds_list_cap = world_hits ? (uint32_t)world_hits : 1u;
             unsigned char* d_image = nullptr;
             rc = upload(image.data(), image.size(), &d_image);
             if (d_image) s->allocations.push_back(d_image);

@@ -68,6 +68,7 @@ struct SceneDev {
     const unsigned char* __restrict__ stage;
     uint32_t stage_bytes;
     uint32_t stage_off[5];
+    uint32_t lds_list_cap;  // staged scenes: the most entries World::intersections can return = per-lane list slots in LDS
 };
 
 // ---- event counters (RtStats order) ------------------------------------------
@@ -112,21 +113,25 @@ struct Scratch : LevelState {
 };
 // ... or in LDS, for small scenes whose world list provably fits RT_LDS_LIST_CAP entries:
 // entry i of lane l sits at [i][l], so a wave's accesses to one entry are conflict-free.
+#ifndef RT_LDS_LIST_CAP
 #define RT_LDS_LIST_CAP 12
-#define RT_LDS_LIST_BYTES (256u * RT_LDS_LIST_CAP * 16u)  // per 256-thread block: t (8) + id (4) + container (4)
+#endif
+#define RT_LDS_LIST_BYTES(cap) (256u * (cap) * 16u)  // per 256-thread block and entry: t (8) + id (4) + container (4)
 struct ScratchLds : LevelState {
     double* lt;
     uint32_t* lid;
     uint32_t* ct;
-    RT_DEV void attach(unsigned char* block_base, unsigned tid) {
+    int cap_;  // what this scene needs (<= RT_LDS_LIST_CAP): a shorter list leaves LDS to more resident blocks
+    RT_DEV void attach(unsigned char* block_base, unsigned tid, unsigned cap) {
         lt = reinterpret_cast<double*>(block_base) + tid;
-        lid = reinterpret_cast<uint32_t*>(block_base + 256u * RT_LDS_LIST_CAP * 8u) + tid;
-        ct = reinterpret_cast<uint32_t*>(block_base + 256u * RT_LDS_LIST_CAP * 12u) + tid;
+        lid = reinterpret_cast<uint32_t*>(block_base + 256u * cap * 8u) + tid;
+        ct = reinterpret_cast<uint32_t*>(block_base + 256u * cap * 12u) + tid;
+        cap_ = (int)cap;
     }
     RT_DEV double& LT(int i) { return lt[i * 256]; }
     RT_DEV uint32_t& LID(int i) { return lid[i * 256]; }
     RT_DEV uint32_t& CT(int i) { return ct[i * 256]; }
-    RT_DEV int cap() const { return RT_LDS_LIST_CAP; }
+    RT_DEV int cap() const { return cap_; }
 };
 
 // ---- one primitive's own hit set ----------------------------------------------
