@@ -278,10 +278,14 @@ RT_DEV int f64_as_i32(double v) {
     return (int)v;
 }
 
-#ifdef RT_INLINE_PATTERN
-#define RT_PATTERN_FN __device__ __forceinline__
-#else
+// Inlined: as a real call the evaluator made every value live across it (the ray, the whole shading
+// context) go through the calling convention's few callee-saved registers, i.e. scratch memory, once
+// per shaded hit -- ~100 B per pixel of HBM writes in the 3 waves/SIMD variants (pattern.rs -14 %,
+// glass_bubble.rs -20 % inlined).  RT_CALL_PATTERN restores the call for comparison.
+#ifdef RT_CALL_PATTERN
 #define RT_PATTERN_FN __device__ __noinline__
+#else
+#define RT_PATTERN_FN __device__ __forceinline__
 #endif
 #define RT_PATTERN_STACK 8  // nesting depth of blend/gradient/radial-gradient nodes
 
