@@ -24,6 +24,9 @@ using namespace rtd;
 #ifndef RT_STAGE_MAX_BYTES
 #define RT_STAGE_MAX_BYTES 16384u  // table image; with the 48 KB LDS list the block stays within 64 KB of dynamic LDS
 #endif
+#ifndef RT_STAGE_MAX_BYTES_COMPOUND
+#define RT_STAGE_MAX_BYTES_COMPOUND 49152u  // scenes with groups / CSG (their lists stay in private memory): two blocks per CU keep 80 KB each
+#endif
 #ifndef RT_WAVES_PER_SIMD_FLAT
 #define RT_WAVES_PER_SIMD_FLAT 2
 #endif
@@ -82,6 +85,13 @@ __global__ __launch_bounds__(256, DENSE ? 3 : (FLAT ? RT_WAVES_PER_SIMD_FLAT : R
         S.mats = reinterpret_cast<const RtMaterial*>(rt_lds + S_in.stage_off[2]);
         S.pats = reinterpret_cast<const RtPattern*>(rt_lds + S_in.stage_off[3]);
         S.lights = reinterpret_cast<const RtLight*>(rt_lds + S_in.stage_off[4]);
+        if constexpr (!FLAT) {  // small scenes with compounds: the traversal's tables too
+            S.groups = reinterpret_cast<const RtGroup*>(rt_lds + S_in.stage_off[5]);
+            S.csgs = reinterpret_cast<const RtCsg*>(rt_lds + S_in.stage_off[6]);
+            S.lhit = reinterpret_cast<const uint8_t*>(rt_lds + S_in.stage_off[7]);
+            S.bvh = reinterpret_cast<const RtBvhNode*>(rt_lds + S_in.stage_off[8]);
+            S.tris = reinterpret_cast<const RtTriangle*>(rt_lds + S_in.stage_off[9]);
+        }
     }
     // 16x16 pixels per block, one 8x8 tile per wave: neighbouring pixels share a wave
     const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -101,8 +111,8 @@ __global__ __launch_bounds__(256, DENSE ? 3 : (FLAT ? RT_WAVES_PER_SIMD_FLAT : R
     }
     if (active) {
         // STAGED scenes are small enough for the per-lane sorted list to live in LDS too
-        typename std::conditional<STAGED, ScratchLds, Scratch>::type W;
-        if constexpr (STAGED) W.attach(rt_lds + ((S_in.stage_bytes + 15u) & ~15u), threadIdx.x, S_in.lds_list_cap);
+        typename std::conditional<STAGED && FLAT, ScratchLds, Scratch>::type W;
+        if constexpr (STAGED && FLAT) W.attach(rt_lds + ((S_in.stage_bytes + 15u) & ~15u), threadIdx.x, S_in.lds_list_cap);
         Frame frames[RT_MAX_DEPTH + 1];
         const Ray ray = ray_for_pixel(cam, x, y);
         count(cx, ST_RAY_PRIMARY);
@@ -136,6 +146,13 @@ __global__ __launch_bounds__(256, FLAT ? RT_WAVES_PER_SIMD_FLAT : RT_WAVES_PER_S
         S.mats = reinterpret_cast<const RtMaterial*>(rt_lds + S_in.stage_off[2]);
         S.pats = reinterpret_cast<const RtPattern*>(rt_lds + S_in.stage_off[3]);
         S.lights = reinterpret_cast<const RtLight*>(rt_lds + S_in.stage_off[4]);
+        if constexpr (!FLAT) {  // small scenes with compounds: the traversal's tables too
+            S.groups = reinterpret_cast<const RtGroup*>(rt_lds + S_in.stage_off[5]);
+            S.csgs = reinterpret_cast<const RtCsg*>(rt_lds + S_in.stage_off[6]);
+            S.lhit = reinterpret_cast<const uint8_t*>(rt_lds + S_in.stage_off[7]);
+            S.bvh = reinterpret_cast<const RtBvhNode*>(rt_lds + S_in.stage_off[8]);
+            S.tris = reinterpret_cast<const RtTriangle*>(rt_lds + S_in.stage_off[9]);
+        }
     }
     Ctx<STATS, FLAT> cx;
     cx.status = 0;
@@ -143,8 +160,8 @@ __global__ __launch_bounds__(256, FLAT ? RT_WAVES_PER_SIMD_FLAT : RT_WAVES_PER_S
 #pragma unroll
         for (int i = 0; i < ST_COUNT; ++i) cx.cnt[i] = 0;
     }
-    typename std::conditional<STAGED, ScratchLds, Scratch>::type W;
-    if constexpr (STAGED) W.attach(rt_lds + ((S_in.stage_bytes + 15u) & ~15u), threadIdx.x, S_in.lds_list_cap);
+    typename std::conditional<STAGED && FLAT, ScratchLds, Scratch>::type W;
+    if constexpr (STAGED && FLAT) W.attach(rt_lds + ((S_in.stage_bytes + 15u) & ~15u), threadIdx.x, S_in.lds_list_cap);
     Frame frames[RT_MAX_DEPTH + 1];
     const unsigned out_shard = ((blockIdx.y * gridDim.x + blockIdx.x) * 4u + (threadIdx.x >> 6)) % RT_WF_SHARDS;  // per wave
     // One pass of one item: color_at up to the end of the lane's first shade_hit, then -- the wave
@@ -578,12 +595,13 @@ int launch_render(const RtScene* scene, const RtCameraDesc* cam, uint32_t depth,
     const dim3 grid((cam->hsize + 15u) / 16u, (rows.n_local_rows + 15u) / 16u);
     if (grid.y > 65535u * 16u) return RT_ERR_INVALID_ARG;
     const bool flat = (scene->dev.flags & RT_SCENE_FLAT) != 0;
-    const bool staged = flat && scene->dev.stage_bytes != 0;
+    const bool staged = scene->dev.stage_bytes != 0;
     // the per-lane list area is read only by the containers walk and by shadow tests among shadowless
     // primitives: a scene with neither leaves the LDS to more resident blocks
     const bool opaque_scene = (scene->dev.flags & RT_SCENE_RECURSIVE) == 0;
     const bool needs_list = !opaque_scene || (scene->dev.flags & RT_SCENE_HAS_SHADOWLESS) != 0;
-    const unsigned lds = staged ? ((scene->dev.stage_bytes + 15u) & ~15u) + (needs_list ? RT_LDS_LIST_BYTES(scene->dev.lds_list_cap) : 0u) : 0u;
+    const unsigned lds = !staged ? 0u
+                         : ((scene->dev.stage_bytes + 15u) & ~15u) + (flat && needs_list ? RT_LDS_LIST_BYTES(scene->dev.lds_list_cap) : 0u);
     // Large scenes whose materials can spawn reflected / refracted rays are traced one generation of rays per
     // launch (dense waves at every depth); the others in one launch, each lane keeping its pixel.  The
     // generations cost ~400 B of queue and node traffic per colour ray, which only pays where a ray is
@@ -610,10 +628,10 @@ int launch_render(const RtScene* scene, const RtCameraDesc* cam, uint32_t depth,
 #define RT_WF_PAIR(ST, FL, SG) wf_level_kernel<ST, FL, SG, true>, wf_level_kernel<ST, FL, SG, false>
         for (unsigned k = 0; k <= depth; ++k) {
             if (d_stats)
-                staged ? level(RT_WF_PAIR(true, true, true), k)
+                staged && flat ? level(RT_WF_PAIR(true, true, true), k)
                        : (flat ? level(RT_WF_PAIR(true, true, false), k) : level(RT_WF_PAIR(true, false, false), k));
             else
-                staged ? level(RT_WF_PAIR(false, true, true), k)
+                staged && flat ? level(RT_WF_PAIR(false, true, true), k)
                        : (flat ? level(RT_WF_PAIR(false, true, false), k) : level(RT_WF_PAIR(false, false, false), k));
             hipLaunchKernelGGL(wf_mark_kernel, dim3(1), dim3(RT_WF_SHARDS), 0, stream, ws, k);
         }
@@ -628,9 +646,10 @@ int launch_render(const RtScene* scene, const RtCameraDesc* cam, uint32_t depth,
     };
     const bool opaque = (scene->dev.flags & RT_SCENE_RECURSIVE) == 0;
     // three blocks per CU need <= 160 KB / 3 of LDS each (and, unstaged, nothing says the denser variant pays)
-    const bool dense = staged && lds <= 53u * 1024u;
+    const bool dense = staged && flat && lds <= 53u * 1024u;
     auto pick = [&](auto stats_tag) {
         constexpr bool ST = decltype(stats_tag)::value;
+        if (!flat && staged) return opaque ? go(render_kernel<ST, false, true, false>) : go(render_kernel<ST, false, true, true>);
         if (!flat) return opaque ? go(render_kernel<ST, false, false, false>) : go(render_kernel<ST, false, false, true>);
         if (!staged) return opaque ? go(render_kernel<ST, true, false, false>) : go(render_kernel<ST, true, false, true>);
         if (opaque) return dense ? go(render_kernel<ST, true, true, false, true>) : go(render_kernel<ST, true, true, false>);
@@ -765,12 +784,13 @@ int rt_hip_scene_create(const RtSceneDesc* desc, RtScene** out) {
     s->dev.g_shapes = shapes, s->dev.g_conics = conics, s->dev.g_tris = tris;
     s->dev.stage = nullptr;
     s->dev.stage_bytes = 0;
-    if (flags & RT_SCENE_FLAT) {  // pack the tables lanes index individually; small scenes shade out of LDS
+    {  // pack the tables lanes index individually: small scenes trace and shade out of an LDS copy
+        const bool is_flat = (flags & RT_SCENE_FLAT) != 0;
         std::vector<unsigned char> image;
         auto put = [&](const void* src, size_t bytes, uint32_t* off) {
             *off = (uint32_t)image.size();
             const unsigned char* b = static_cast<const unsigned char*>(src);
-            image.insert(image.end(), b, b + bytes);
+            if (bytes) image.insert(image.end(), b, b + bytes);
             while (image.size() % 16u) image.push_back(0);
         };
         put(desc->shapes, sizeof(RtShape) * desc->n_shapes, &s->dev.stage_off[0]);
@@ -778,10 +798,19 @@ int rt_hip_scene_create(const RtSceneDesc* desc, RtScene** out) {
         put(desc->materials, sizeof(RtMaterial) * desc->n_materials, &s->dev.stage_off[2]);
         put(desc->patterns, sizeof(RtPattern) * desc->n_patterns, &s->dev.stage_off[3]);
         put(desc->lights, sizeof(RtLight) * desc->n_lights, &s->dev.stage_off[4]);
+        if (!is_flat) {  // what the traversal of compounds reads (FLAT kernels fetch triangles through the scalar cache)
+            put(desc->groups, sizeof(RtGroup) * desc->n_groups, &s->dev.stage_off[5]);
+            put(desc->csgs, sizeof(RtCsg) * desc->n_csgs, &s->dev.stage_off[6]);
+            put(desc->lhit, desc->n_lhit, &s->dev.stage_off[7]);
+            put(desc->bvh_nodes, sizeof(RtBvhNode) * desc->n_bvh_nodes, &s->dev.stage_off[8]);
+            put(desc->triangles, sizeof(RtTriangle) * desc->n_triangles, &s->dev.stage_off[9]);
+        }
         uint64_t world_hits = 0;  // most entries World::intersections can return: the per-lane list must hold them
         for (uint32_t i = 0; i < desc->n_shapes; ++i) world_hits += max_hits_of_kind(RT_KIND(desc->shapes[i].kind_flags));
-        if (!image.empty() && image.size() <= RT_STAGE_MAX_BYTES && world_hits <= RT_LDS_LIST_CAP) {
-            s->dev.lds_list_cap = world_hits ? (uint32_t)world_hits : 1u;
+        const bool fits = is_flat ? image.size() <= RT_STAGE_MAX_BYTES && world_hits <= RT_LDS_LIST_CAP
+                                  : image.size() <= RT_STAGE_MAX_BYTES_COMPOUND;
+        if (!image.empty() && fits) {
+            s->dev.lds_list_cap = !is_flat ? 0u : (world_hits ? (uint32_t)world_hits : 1u);
             unsigned char* d_image = nullptr;
             rc = upload(image.data(), image.size(), &d_image);
             if (d_image) s->allocations.push_back(d_image);

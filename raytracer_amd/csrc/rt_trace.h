@@ -67,7 +67,7 @@ struct SceneDev {
     // repoints the five table pointers above at its LDS copy.
     const unsigned char* __restrict__ stage;
     uint32_t stage_bytes;
-    uint32_t stage_off[5];
+    uint32_t stage_off[10];  // shapes conics mats pats lights | scenes with compounds also: groups csgs lhit bvh tris
     uint32_t lds_list_cap;  // staged scenes: the most entries World::intersections can return = per-lane list slots in LDS
 };
 
