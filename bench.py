@@ -146,6 +146,19 @@ def main():
     scene.status()
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
 
+    # tracing, gather and device-to-host times separately.  The copy of the finished frame to
+    # host memory is outside the timed steps (inputs and outputs stay resident); one copy is timed here.
+    d2h_ms = None
+    if rank == 0:
+        final = frame if n_parts > 1 else shard[:H]
+        host = torch.empty(final.shape, dtype=final.dtype, pin_memory=True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        host.copy_(final)
+        torch.cuda.synchronize()
+        d2h_ms = (time.perf_counter() - t1) * 1e3
+        del host
+
     t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
     if n_parts > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -174,6 +187,10 @@ def main():
                 "width": W, "height": H, "depth": args.depth, "band_rows": band,
                 "parallelism": f"row-bands x{n_parts}" + (" + RCCL gather to rank 0" if n_parts > 1 else ""),
                 "rays_per_frame": int(rays_per_frame), "mpixels_per_s": round(W * H * args.steps / elapsed / 1e6, 3),
+                # per step: slowest rank's render launches (HIP events); the rest of the step = RCCL gather + row permutation
+                # on the root; and, outside the timed steps, one copy of the finished f64 frame to pinned host memory
+                "trace_ms": round(kernel_ms_max, 4), "gather_ms": round(max(ms_per_step - kernel_ms_max, 0.0), 4) if n_parts > 1 else 0.0,
+                "d2h_ms": round(d2h_ms, 3),
             },
             "roofline": {
                 "bound": "valu_f64",
