@@ -271,6 +271,14 @@ int rt_hip_render(const RtSceneDesc* desc, const RtCameraDesc* cam, uint32_t dep
 int rt_hip_render_rgb8(const RtSceneDesc* desc, const RtCameraDesc* cam, uint32_t depth, uint8_t* out_rgb8,
                        RtStats* stats);
 
+/* The same two calls on a scene that stays resident (rt_hip_scene_create): camera-only changes between
+ * frames -- a fly-through, a re-render at another size -- then cost the kernel and the copy out, not the
+ * flattening and upload.  The device framebuffers belong to the scene and are
+ * reused.  Replaces: `camera.render(&world)` called again with the same `world` (camera.rs:51). */
+int rt_hip_scene_render(const RtScene* scene, const RtCameraDesc* cam, uint32_t depth, double* out_rgb, RtStats* stats);
+int rt_hip_scene_render_rgb8(const RtScene* scene, const RtCameraDesc* cam, uint32_t depth, uint8_t* out_rgb8,
+                             RtStats* stats);
+
 /* Same path with everything resident: renders a subset of image rows of a
  * device-resident scene into DEVICE memory, asynchronously on `hip_stream`
  * (a hipStream_t, NULL = default stream).  Local row k (0 <= k < n_local_rows)

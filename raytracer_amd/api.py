@@ -412,6 +412,24 @@ class DeviceScene:
                                          C.c_void_p(d_out_ptr), C.c_void_p(stream or 0), C.c_void_p(d_stats_ptr or 0)),
                 "rt_hip_render_rows")
 
+    def render(self, camera, stats=False):
+        """`camera.render(&world)` on the resident scene (rt_hip_scene_render): Canvas of f64 colours."""
+        out = np.empty((camera.v_size, camera.h_size, 3), dtype=np.float64)
+        cd = camera.desc()
+        st = N.RtStats() if stats else None
+        N.check(N.hip.rt_hip_scene_render(self._p, C.byref(cd), Camera.DEPTH, _dp(out), C.byref(st) if stats else None),
+                "rt_hip_scene_render")
+        canvas = Canvas(camera.h_size, camera.v_size, out)
+        return (canvas, st) if stats else canvas
+
+    def render_rgb8(self, camera):
+        """... as the 8-bit samples of Canvas::to_ppm, quantised on the device -> uint8 [v, h, 3]."""
+        out = np.empty((camera.v_size, camera.h_size, 3), dtype=np.uint8)
+        cd = camera.desc()
+        N.check(N.hip.rt_hip_scene_render_rgb8(self._p, C.byref(cd), Camera.DEPTH, out.ctypes.data_as(C.POINTER(C.c_uint8)), None),
+                "rt_hip_scene_render_rgb8")
+        return out
+
     def set_wavefront(self, mode=-1, queue_items=0, node_items=0):
         """rt_hip_scene_set_wavefront: -1 by policy, 0 one launch, 1 one launch per generation of rays."""
         N.check(N.hip.rt_hip_scene_set_wavefront(self._p, mode, queue_items, node_items), "rt_hip_scene_set_wavefront")

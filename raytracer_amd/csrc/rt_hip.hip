@@ -567,6 +567,9 @@ struct RtScene {
     // launches on one scene are not re-entrant, so it is simply reused
     mutable WfSpace wf;
     mutable size_t wf_pixels;
+    mutable double* d_frame;           // rt_hip_scene_render*: device framebuffers, grown to the largest frame asked for
+    mutable uint8_t* d_frame8;
+    mutable size_t frame_values;
     int wf_mode;                       // rt_hip_scene_set_wavefront: -1 by policy, 0 never, 1 whenever the scene can recurse
     size_t wf_q_items, wf_node_items;  // capacities asked for (0: the defaults, per pixel of the frame)
 };
@@ -794,6 +797,7 @@ int rt_hip_scene_create(const RtSceneDesc* desc, RtScene** out) {
     s->device = g_device;
     std::memset(&s->wf, 0, sizeof s->wf);
     s->wf_pixels = 0;
+    s->d_frame = nullptr, s->d_frame8 = nullptr, s->frame_values = 0;
     s->wf_mode = -1;
     s->wf_q_items = s->wf_node_items = 0;
     for (uint32_t k = 0; k < desc->n_materials; ++k)  // world.rs:99,110: these are the only tests that let color_at recurse
@@ -905,6 +909,8 @@ int rt_hip_scene_create(const RtSceneDesc* desc, RtScene** out) {
 void rt_hip_scene_destroy(RtScene* scene) {
     if (!scene) return;
     for (void* p : scene->allocations) (void)hipFree(p);
+    if (scene->d_frame) (void)hipFree(scene->d_frame);
+    if (scene->d_frame8) (void)hipFree(scene->d_frame8);
     for (void* p : {(void*)scene->wf.queue[0], (void*)scene->wf.queue[1], (void*)scene->wf.nodes, (void*)scene->wf.shards})
         if (p) (void)hipFree(p);
     delete scene;
@@ -938,22 +944,27 @@ int rt_hip_render_rows(const RtScene* scene, const RtCameraDesc* cam, uint32_t d
 }
 
 // Camera::render with the frame returned as f64 colours (out_rgb) or as the 8-bit samples Canvas::to_ppm prints (out_rgb8)
-static int render_to_host(const RtSceneDesc* desc, const RtCameraDesc* cam, uint32_t depth, double* out_rgb,
-                          uint8_t* out_rgb8, RtStats* stats) {
-    if (!out_rgb && !out_rgb8) return RT_ERR_INVALID_ARG;
-    int rc = check_camera(cam, depth);
-    if (rc != RT_OK) return rc;
-    RtScene* scene = nullptr;
-    rc = rt_hip_scene_create(desc, &scene);
-    if (rc != RT_OK) return rc;
+// Camera::render on a resident scene, the frame returned as f64 colours (out_rgb) and / or as the 8-bit
+// samples Canvas::to_ppm prints (out_rgb8).  The device framebuffers belong to the scene and are reused.
+static int scene_render_to_host(const RtScene* scene, const RtCameraDesc* cam, uint32_t depth, double* out_rgb,
+                                uint8_t* out_rgb8, RtStats* stats) {
+    if (!scene || (!out_rgb && !out_rgb8)) return RT_ERR_INVALID_ARG;
+    const int crc0 = check_camera(cam, depth);
+    if (crc0 != RT_OK) return crc0;
     const size_t n_values = (size_t)cam->hsize * cam->vsize * 3u;
-    double* d_out = nullptr;
-    uint8_t* d_out8 = nullptr;
+    if (scene->frame_values < n_values) {
+        if (scene->d_frame) (void)hipFree(scene->d_frame);
+        if (scene->d_frame8) (void)hipFree(scene->d_frame8);
+        scene->d_frame = nullptr, scene->d_frame8 = nullptr, scene->frame_values = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&scene->d_frame), n_values * sizeof(double)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&scene->d_frame8), n_values));
+        scene->frame_values = n_values;
+    }
+    double* d_out = scene->d_frame;
+    uint8_t* d_out8 = scene->d_frame8;
     RtStats* d_stats = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     auto body = [&]() -> int {
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_out), n_values * sizeof(double)));
-        if (out_rgb8) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_out8), n_values));
         if (stats) {
             HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_stats), sizeof(RtStats)));
             HIP_TRY(hipMemset(d_stats, 0, sizeof(RtStats)));
@@ -985,14 +996,35 @@ static int render_to_host(const RtSceneDesc* desc, const RtCameraDesc* cam, uint
         }
         return src;
     };
-    rc = body();
+    const int rc = body();
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
-    if (d_out) (void)hipFree(d_out);
-    if (d_out8) (void)hipFree(d_out8);
     if (d_stats) (void)hipFree(d_stats);
+    return rc;
+}
+
+static int render_to_host(const RtSceneDesc* desc, const RtCameraDesc* cam, uint32_t depth, double* out_rgb,
+                          uint8_t* out_rgb8, RtStats* stats) {
+    if (!out_rgb && !out_rgb8) return RT_ERR_INVALID_ARG;
+    int rc = check_camera(cam, depth);
+    if (rc != RT_OK) return rc;
+    RtScene* scene = nullptr;
+    rc = rt_hip_scene_create(desc, &scene);
+    if (rc != RT_OK) return rc;
+    rc = scene_render_to_host(scene, cam, depth, out_rgb, out_rgb8, stats);
     rt_hip_scene_destroy(scene);
     return rc;
+}
+
+int rt_hip_scene_render(const RtScene* scene, const RtCameraDesc* cam, uint32_t depth, double* out_rgb, RtStats* stats) {
+    if (!out_rgb) return RT_ERR_INVALID_ARG;
+    return scene_render_to_host(scene, cam, depth, out_rgb, nullptr, stats);
+}
+
+int rt_hip_scene_render_rgb8(const RtScene* scene, const RtCameraDesc* cam, uint32_t depth, uint8_t* out_rgb8,
+                             RtStats* stats) {
+    if (!out_rgb8) return RT_ERR_INVALID_ARG;
+    return scene_render_to_host(scene, cam, depth, nullptr, out_rgb8, stats);
 }
 
 int rt_hip_render(const RtSceneDesc* desc, const RtCameraDesc* cam, uint32_t depth, double* out_rgb, RtStats* stats) {

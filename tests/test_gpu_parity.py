@@ -189,3 +189,21 @@ def test_generation_per_launch_equals_one_launch(name, width, height):
     assert np.array_equal(mono, _render_resident(scene, cam, -1))
     ref, _ = orc.OracleWorld(world.describe()).render(cam)
     compare(f"{name}-generations", wave, ref)
+
+
+def test_resident_scene_renders_equal_one_shot_renders():
+    """rt_hip_scene_render / _rgb8: a scene kept on the device, rendered from several cameras and at
+    several sizes (the scene's framebuffers grow and are reused), gives what `camera.render(&world)`
+    gives for each camera -- flatten, upload and all -- bit for bit."""
+    world, cam0 = rt.exercise("cover", 160, 90)
+    scene = rt.DeviceScene(world.flatten())
+    cams = [cam0,
+            rt.Camera(96, 54, 0.9).with_transform(rt.Matrix.view_transform((-4, 5, -9), (5, -1, 5), (-0.4, 1, 0))),
+            rt.Camera(240, 135, 0.7).with_transform(rt.Matrix.view_transform((-7, 7, -11), (6, -2, 6), (-0.45, 1, 0))),
+            rt.Camera(33, 17, 1.2).with_transform(rt.Matrix.view_transform((0, 2, -12), (0, 0, 0), (0, 1, 0)))]
+    for cam in cams:
+        one_shot = cam.render(world).pixels
+        resident, st = scene.render(cam, stats=True)
+        assert np.array_equal(resident.pixels, one_shot)
+        assert st.rays_primary == cam.h_size * cam.v_size
+        assert np.array_equal(scene.render_rgb8(cam), orc.quantize(one_shot))
