@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <fstream>
 #include <sstream>
+#include <string_view>
 #include <thread>
 #include <unordered_map>
 
@@ -205,12 +206,13 @@ bool Primitive::structural_eq(const Primitive& o) const {
 }
 
 // ----------------------------------------------------------------- Compound ---
-Compound Compound::new_group(const std::vector<Shape>& children) {
+Compound Compound::new_group(const std::vector<Shape>& children) { return new_group(std::vector<Shape>(children)); }
+Compound Compound::new_group(std::vector<Shape>&& children) {
     Compound c;
     c.kind_ = Kind::Group;
-    c.children_ = std::make_shared<const std::vector<Shape>>(children);
+    c.children_ = std::make_shared<const std::vector<Shape>>(std::move(children));
     Bounds b;  // compound.rs:29-36: union with the child's box, then grow by the child's transform
-    for (const Shape& child : children) {
+    for (const Shape& child : *c.children_) {
         b.union_with(child.properties().bounds);
         b.transform(child.properties().transform);
     }
@@ -419,16 +421,21 @@ Camera Camera::with_transform(const Matrix4& t) const {
 // --------------------------------------------------------------------- OBJ ---
 namespace obj {
 namespace {
-// Rust's str::parse::<f64>: decimal float syntax, whole token, no whitespace.
-bool parse_f64(const std::string& s, double& out) {
+// Tokens are views into the text: the teapot is 45 000 lines, and a std::string per token was most of
+// the parse time.
+using Tok = std::string_view;
+
+// Rust's str::parse::<f64>: decimal float syntax, whole token, no whitespace.  The token is followed in
+// the text by a separator or the terminating NUL, where strtod stops by itself.
+bool parse_f64(Tok s, double& out) {
     if (s.empty() || std::isspace(static_cast<unsigned char>(s[0]))) return false;
-    if (s.find_first_of("xX") != std::string::npos) return false;  // strtod would take hex floats
+    if (s.find_first_of("xX") != Tok::npos) return false;  // strtod would take hex floats
     char* end = nullptr;
     errno = 0;
-    out = std::strtod(s.c_str(), &end);
-    return end == s.c_str() + s.size();
+    out = std::strtod(s.data(), &end);
+    return end == s.data() + s.size();
 }
-bool parse_usize(const std::string& s, size_t& out) {
+bool parse_usize(Tok s, size_t& out) {
     if (s.empty()) return false;
     size_t i = (s[0] == '+') ? 1 : 0;  // usize::from_str accepts a leading '+'
     if (i == s.size()) return false;
@@ -440,21 +447,21 @@ bool parse_usize(const std::string& s, size_t& out) {
     out = v;
     return true;
 }
-std::vector<std::string> split(const std::string& s, char sep) {
-    std::vector<std::string> parts;
+// str::split(sep): every separator ends a (possibly empty) part; `parts` is reused between lines
+void split(Tok s, char sep, std::vector<Tok>& parts) {
+    parts.clear();
     size_t start = 0;
     while (true) {
         const size_t pos = s.find(sep, start);
-        if (pos == std::string::npos) {
+        if (pos == Tok::npos) {
             parts.push_back(s.substr(start));
             break;
         }
         parts.push_back(s.substr(start, pos - start));
         start = pos + 1;
     }
-    return parts;
 }
-std::string trim(const std::string& s) {
+Tok trim(Tok s) {
     size_t b = 0, e = s.size();
     while (b < e && std::isspace(static_cast<unsigned char>(s[b]))) ++b;
     while (e > b && std::isspace(static_cast<unsigned char>(s[e - 1]))) --e;
@@ -465,37 +472,45 @@ struct VertexRef {
     bool has_n = false;
     Vector n;
 };
-VertexRef parse_vertex_ref(const std::string& v, const std::vector<Point>& vertices,
-                           const std::vector<Vector>& normals) {  // obj.rs:164-185
-    const auto parts = split(v, '/');
+VertexRef parse_vertex_ref(Tok v, const std::vector<Point>& vertices, const std::vector<Vector>& normals) {  // obj.rs:164-185
+    Tok parts[3];
+    size_t n_parts = 0, start = 0;
+    while (true) {  // split('/')
+        const size_t pos = v.find('/', start);
+        const Tok part = pos == Tok::npos ? v.substr(start) : v.substr(start, pos - start);
+        if (n_parts < 3) parts[n_parts] = part;
+        ++n_parts;
+        if (pos == Tok::npos) break;
+        start = pos + 1;
+    }
     const auto bad = [&]() {
         return ParseError(ParseError::Kind::Syntax,
-                          "Syntax error, indices must be natural numbers, given: " + v);
+                          "Syntax error, indices must be natural numbers, given: " + std::string(v));
     };
     VertexRef r;
     size_t vi = 0, ni = 0;
-    if (parts.size() == 3) {
+    if (n_parts == 3) {
         if (!parse_usize(parts[0], vi) || !parse_usize(parts[2], ni)) throw bad();
         r.p = vertices.at(vi - 1);  // out of range panics in the reference
         r.n = normals.at(ni - 1);
         r.has_n = true;
-    } else if (parts.size() == 1 || parts.size() == 2) {
+    } else if (n_parts == 1 || n_parts == 2) {
         if (!parse_usize(parts[0], vi)) throw bad();
         r.p = vertices.at(vi - 1);
     } else {
-        throw ParseError(ParseError::Kind::Syntax, "Syntax error, invalid vertex ref: " + v);
+        throw ParseError(ParseError::Kind::Syntax, "Syntax error, invalid vertex ref: " + std::string(v));
     }
     return r;
 }
-Primitive parse_triangle(const std::string& a, const std::string& b, const std::string& c,
-                         const std::vector<Point>& vertices, const std::vector<Vector>& normals) {
+Primitive parse_triangle(Tok a, Tok b, Tok c, const std::vector<Point>& vertices, const std::vector<Vector>& normals) {
     const VertexRef r1 = parse_vertex_ref(a, vertices, normals);
     const VertexRef r2 = parse_vertex_ref(b, vertices, normals);
     const VertexRef r3 = parse_vertex_ref(c, vertices, normals);
     if (r1.has_n && r2.has_n && r3.has_n)
         return Primitive::new_smooth_triangle(r1.p, r2.p, r3.p, r1.n, r2.n, r3.n);
     if (!r1.has_n && !r2.has_n && !r3.has_n) return Primitive::new_triangle(r1.p, r2.p, r3.p);
-    throw ParseError(ParseError::Kind::Syntax, "Syntax error, invalid triangle: " + a + " " + b + " " + c);
+    throw ParseError(ParseError::Kind::Syntax, "Syntax error, invalid triangle: " + std::string(a) + " " +
+                                                   std::string(b) + " " + std::string(c));
 }
 }  // namespace
 
@@ -509,54 +524,66 @@ Shape parse_string(const std::string& text, size_t* ignored_lines) {
     std::unordered_map<std::string, std::vector<Primitive>> groups;
     bool have_group = false;
     std::string current_group;
+    std::vector<Primitive>* current = nullptr;  // the open group's triangles, once it has any
     size_t ignored = 0;
 
-    std::istringstream in(text);
-    std::string line;
-    while (std::getline(in, line)) {
-        if (!line.empty() && line.back() == '\r') line.pop_back();  // str::lines strips \r\n
-        const auto tok = split(trim(line), ' ');                   // obj.rs:76: single-space split
+    const Tok all(text);
+    std::vector<Tok> tok;
+    size_t at = 0;
+    while (at < all.size()) {  // str::lines: split at \n, a trailing \r goes with it, no empty last line
+        const size_t nl = all.find('\n', at);
+        Tok line = nl == Tok::npos ? all.substr(at) : all.substr(at, nl - at);
+        at = nl == Tok::npos ? all.size() : nl + 1;
+        if (!line.empty() && line.back() == '\r') line.remove_suffix(1);
+        split(trim(line), ' ', tok);  // obj.rs:76: single-space split
         if (tok.size() == 4 && (tok[0] == "v" || tok[0] == "vn")) {
             double x, y, z;
             if (!parse_f64(tok[1], x) || !parse_f64(tok[2], y) || !parse_f64(tok[3], z))
                 throw ParseError(ParseError::Kind::Syntax,
-                                 std::string("Syntax error, invalid ") + (tok[0] == "v" ? "vertex" : "normal") +
-                                     ": " + tok[1] + " " + tok[2] + " " + tok[3]);
+                                 std::string("Syntax error, invalid ") + (tok[0] == "v" ? "vertex" : "normal") + ": " +
+                                     std::string(tok[1]) + " " + std::string(tok[2]) + " " + std::string(tok[3]));
             if (tok[0] == "v")
                 vertices.emplace_back(x, y, z);
             else
                 normals.emplace_back(x, y, z);
         } else if (tok.size() >= 4 && tok[0] == "f") {
-            std::vector<Primitive> ts;  // fan triangulation, obj.rs:132-140
-            for (size_t i = 2; i + 1 < tok.size(); ++i)
-                ts.push_back(parse_triangle(tok[1], tok[i], tok[i + 1], vertices, normals));
-            if (have_group) {
-                auto it = groups.find(current_group);
-                if (it == groups.end()) {
-                    group_order.push_back(current_group);
-                    it = groups.emplace(current_group, std::vector<Primitive>()).first;
+            for (size_t i = 2; i + 1 < tok.size(); ++i) {  // fan triangulation, obj.rs:132-140
+                Primitive t = parse_triangle(tok[1], tok[i], tok[i + 1], vertices, normals);
+                if (!have_group) {
+                    shapes.push_back(t.to_shape());
+                    continue;
                 }
-                it->second.insert(it->second.end(), ts.begin(), ts.end());
-            } else {
-                for (const Primitive& t : ts) shapes.push_back(t.to_shape());
+                if (!current) {  // a group exists from its first face on
+                    auto it = groups.find(current_group);
+                    if (it == groups.end()) {
+                        group_order.push_back(current_group);
+                        it = groups.emplace(current_group, std::vector<Primitive>()).first;
+                    }
+                    current = &it->second;
+                }
+                current->push_back(std::move(t));
             }
         } else if (tok.size() == 2 && tok[0] == "g") {
             have_group = true;
-            current_group = tok[1];
+            current_group = std::string(tok[1]);
+            current = nullptr;
         } else {
             ++ignored;
         }
     }
     if (ignored_lines) *ignored_lines = ignored;
 
+    shapes.reserve(shapes.size() + group_order.size());
     for (const std::string& name : group_order) {  // obj.rs:40-45
+        std::vector<Primitive>& members = groups[name];
         std::vector<Shape> kids;
-        for (const Primitive& t : groups[name]) kids.push_back(t.to_shape());
-        shapes.push_back(Compound::new_group(kids).to_shape());
+        kids.reserve(members.size());
+        for (Primitive& t : members) kids.push_back(t.to_shape());
+        shapes.push_back(Compound::new_group(std::move(kids)).to_shape());
     }
     if (shapes.empty()) throw ParseError(ParseError::Kind::Logic, "Logic error, no shapes found");
-    if (shapes.size() == 1) return shapes.back();
-    return Compound::new_group(shapes).to_shape();
+    if (shapes.size() == 1) return std::move(shapes.back());
+    return Compound::new_group(std::move(shapes)).to_shape();
 }
 
 Shape parse_file(const std::string& path) {

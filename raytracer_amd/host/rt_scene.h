@@ -188,6 +188,7 @@ class Compound {
 public:
     enum class Kind : uint32_t { Group = 7, Csg = 8 };
     static Compound new_group(const std::vector<Shape>& children);
+    static Compound new_group(std::vector<Shape>&& children);  // takes the vector over (large OBJ groups)
     static Compound new_csg(Operation op, const Shape& left, const Shape& right);
 
     Compound with_transform(const Matrix4& t) const;
