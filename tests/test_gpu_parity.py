@@ -207,3 +207,33 @@ def test_resident_scene_renders_equal_one_shot_renders():
         assert np.array_equal(resident.pixels, one_shot)
         assert st.rays_primary == cam.h_size * cam.v_size
         assert np.array_equal(scene.render_rgb8(cam), orc.quantize(one_shot))
+
+
+def test_generations_with_row_bands_and_other_budgets():
+    """The generation-per-launch kernels under what a multi-GPU job asks of them -- interleaved row bands
+    rendered shard by shard on one scene (the workspace is reused, sized by the largest shard) -- and at
+    recursion budgets other than camera.rs:59's 5: always the one-launch kernel's frame, bit for bit."""
+    import torch
+    from raytracer_amd import tiling
+    W, H = 203, 117  # ragged on purpose: not a multiple of the 16x16 tiles nor of the band height
+    world, cam = rt.synthetic(W, H, 1200)
+    scene = rt.DeviceScene(world.flatten())
+    cd = cam.desc()
+
+    def frame(mode, depth, n_parts=1, band=tiling.DEFAULT_BAND_ROWS):
+        scene.set_wavefront(mode)
+        slots = tiling.padded_local_rows(H, n_parts, band)
+        shards = []
+        for part in range(n_parts):
+            buf = torch.full((slots, W, 3), -3.0, dtype=torch.float64, device="cuda")
+            scene.render_rows(cd, depth, part, n_parts, band, tiling.n_local_rows(H, part, n_parts, band), buf.data_ptr())
+            shards.append(buf)
+        torch.cuda.synchronize()
+        scene.status()
+        return tiling.assemble(shards, H, n_parts, band).cpu().numpy()
+
+    for depth in (0, 1, 2, 5, 8):
+        assert np.array_equal(frame(0, depth), frame(1, depth)), depth
+    whole = frame(0, 5)
+    for n_parts, band in ((3, 16), (8, 16), (2, 5)):
+        assert np.array_equal(frame(1, 5, n_parts, band), whole), (n_parts, band)
