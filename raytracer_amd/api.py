@@ -385,7 +385,9 @@ class FlatScene(_Handle):
     _free = N.host.rth_flat_free
 
     def __init__(self, world, build_bvh=True):
-        super().__init__(N.host.rth_world_flatten(world._p, 1 if build_bvh else 0), "flatten")
+        # build_bvh: False / True (by policy), or "nested" / "global" to force one form of hierarchy
+        mode = {"nested": 2, "global": 3}.get(build_bvh, 1 if build_bvh else 0)
+        super().__init__(N.host.rth_world_flatten(world._p, mode), "flatten")
         self.desc = N.host.rth_flat_desc(self._p)  # POINTER(RtSceneDesc), valid while self lives
 
 

@@ -42,7 +42,7 @@ struct RowMap {  // local row k -> image row (rt_hip_render_rows)
     uint32_t part, n_parts, band_rows, n_local_rows;
 };
 
-template <bool STATS, bool FLAT>
+template <bool STATS, int FLAT>
 __device__ void flush_stats(Ctx<STATS, FLAT>& cx, RtStats* __restrict__ stats, unsigned* __restrict__ status) {
     if (cx.status) atomicOr(status, cx.status);
     if constexpr (STATS) {
@@ -71,8 +71,8 @@ extern __shared__ __align__(16) unsigned char rt_lds[];
 // DENSE: 3 waves/SIMD (168 VGPRs, a few spilled) instead of 2 -- FLAT scenes whose LDS share lets three
 // blocks live on a CU.  Measured on pattern.rs (no recursion) at 2 / 3 / 4 waves/SIMD: 0.97 / 0.83 /
 // 1.02 ms; glass_bubble.rs 4.83 / 4.50 / -; the general kernel gains nothing (profiles/r01_variants.txt).
-template <bool STATS, bool FLAT, bool STAGED, bool RECURSE = true, bool DENSE = false>
-__global__ __launch_bounds__(256, DENSE ? 3 : (FLAT ? RT_WAVES_PER_SIMD_FLAT : RT_WAVES_PER_SIMD)) void render_kernel(const SceneDev S_in, RtCameraDesc cam, int depth, RowMap rows,
+template <bool STATS, int FLAT, bool STAGED, bool RECURSE = true, bool DENSE = false>
+__global__ __launch_bounds__(256, DENSE ? 3 : (FLAT == RT_CLASS_FLAT ? RT_WAVES_PER_SIMD_FLAT : RT_WAVES_PER_SIMD)) void render_kernel(const SceneDev S_in, RtCameraDesc cam, int depth, RowMap rows,
                                                      double* __restrict__ out, RtStats* __restrict__ stats,
                                                      unsigned* __restrict__ status) {
     SceneDev S = S_in;
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256, DENSE ? 3 : (FLAT ? RT_WAVES_PER_SIMD_FLAT : R
         S.mats = reinterpret_cast<const RtMaterial*>(rt_lds + S_in.stage_off[2]);
         S.pats = reinterpret_cast<const RtPattern*>(rt_lds + S_in.stage_off[3]);
         S.lights = reinterpret_cast<const RtLight*>(rt_lds + S_in.stage_off[4]);
-        if constexpr (!FLAT) {  // small scenes with compounds: the traversal's tables too
+        if constexpr (FLAT != RT_CLASS_FLAT) {  // small scenes with compounds: the traversal's tables too
             S.groups = reinterpret_cast<const RtGroup*>(rt_lds + S_in.stage_off[5]);
             S.csgs = reinterpret_cast<const RtCsg*>(rt_lds + S_in.stage_off[6]);
             S.lhit = reinterpret_cast<const uint8_t*>(rt_lds + S_in.stage_off[7]);
@@ -112,8 +112,8 @@ __global__ __launch_bounds__(256, DENSE ? 3 : (FLAT ? RT_WAVES_PER_SIMD_FLAT : R
     }
     if (active) {
         // STAGED scenes are small enough for the per-lane sorted list to live in LDS too
-        typename std::conditional<STAGED && FLAT, ScratchLds, Scratch>::type W;
-        if constexpr (STAGED && FLAT) W.attach(rt_lds + ((S_in.stage_bytes + 15u) & ~15u), threadIdx.x, S_in.lds_list_cap);
+        typename std::conditional<STAGED && FLAT == RT_CLASS_FLAT, ScratchLds, Scratch>::type W;
+        if constexpr (STAGED && FLAT == RT_CLASS_FLAT) W.attach(rt_lds + ((S_in.stage_bytes + 15u) & ~15u), threadIdx.x, S_in.lds_list_cap);
         Frame frames[RT_MAX_DEPTH + 1];
         const Ray ray = ray_for_pixel(cam, x, y);
         count(cx, ST_RAY_PRIMARY);
@@ -132,8 +132,8 @@ __global__ __launch_bounds__(256, DENSE ? 3 : (FLAT ? RT_WAVES_PER_SIMD_FLAT : R
 // slice b % RT_WF_SHARDS together with the other blocks of that slice.
 // (Nothing the cold no-room path needs is kept in registers across color_at: it re-reads its item,
 // or the camera record from the workspace.)
-template <bool STATS, bool FLAT, bool STAGED, bool PRIMARY>
-__global__ __launch_bounds__(256, FLAT ? RT_WAVES_PER_SIMD_FLAT : RT_WAVES_PER_SIMD) void wf_level_kernel(
+template <bool STATS, int FLAT, bool STAGED, bool PRIMARY>
+__global__ __launch_bounds__(256, FLAT == RT_CLASS_FLAT ? RT_WAVES_PER_SIMD_FLAT : RT_WAVES_PER_SIMD) void wf_level_kernel(
     const SceneDev S_in, RtCameraDesc cam, int depth, RowMap rows, double* __restrict__ out, RtStats* __restrict__ stats,
     unsigned* __restrict__ status, WfSpace ws, unsigned level) {
     SceneDev S = S_in;
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256, FLAT ? RT_WAVES_PER_SIMD_FLAT : RT_WAVES_PER_S
         S.mats = reinterpret_cast<const RtMaterial*>(rt_lds + S_in.stage_off[2]);
         S.pats = reinterpret_cast<const RtPattern*>(rt_lds + S_in.stage_off[3]);
         S.lights = reinterpret_cast<const RtLight*>(rt_lds + S_in.stage_off[4]);
-        if constexpr (!FLAT) {  // small scenes with compounds: the traversal's tables too
+        if constexpr (FLAT != RT_CLASS_FLAT) {  // small scenes with compounds: the traversal's tables too
             S.groups = reinterpret_cast<const RtGroup*>(rt_lds + S_in.stage_off[5]);
             S.csgs = reinterpret_cast<const RtCsg*>(rt_lds + S_in.stage_off[6]);
             S.lhit = reinterpret_cast<const uint8_t*>(rt_lds + S_in.stage_off[7]);
@@ -161,8 +161,8 @@ __global__ __launch_bounds__(256, FLAT ? RT_WAVES_PER_SIMD_FLAT : RT_WAVES_PER_S
 #pragma unroll
         for (int i = 0; i < ST_COUNT; ++i) cx.cnt[i] = 0;
     }
-    typename std::conditional<STAGED && FLAT, ScratchLds, Scratch>::type W;
-    if constexpr (STAGED && FLAT) W.attach(rt_lds + ((S_in.stage_bytes + 15u) & ~15u), threadIdx.x, S_in.lds_list_cap);
+    typename std::conditional<STAGED && FLAT == RT_CLASS_FLAT, ScratchLds, Scratch>::type W;
+    if constexpr (STAGED && FLAT == RT_CLASS_FLAT) W.attach(rt_lds + ((S_in.stage_bytes + 15u) & ~15u), threadIdx.x, S_in.lds_list_cap);
     Frame frames[RT_MAX_DEPTH + 1];
     const unsigned out_shard = ((blockIdx.y * gridDim.x + blockIdx.x) * 4u + (threadIdx.x >> 6)) % RT_WF_SHARDS;  // per wave
     // One pass of one item: color_at up to the end of the lane's first shade_hit, then -- the wave
@@ -257,8 +257,8 @@ __global__ __launch_bounds__(256) void wf_combine_kernel(WfSpace ws, unsigned le
     }
 }
 
-template <bool FLAT>
-__global__ __launch_bounds__(256, FLAT ? RT_WAVES_PER_SIMD_FLAT : RT_WAVES_PER_SIMD) void color_at_kernel(const SceneDev S, const double* __restrict__ rays,
+template <int FLAT>
+__global__ __launch_bounds__(256, FLAT == RT_CLASS_FLAT ? RT_WAVES_PER_SIMD_FLAT : RT_WAVES_PER_SIMD) void color_at_kernel(const SceneDev S, const double* __restrict__ rays,
                                                        unsigned n, int depth, double* __restrict__ out,
                                                        unsigned* __restrict__ status) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256, FLAT ? RT_WAVES_PER_SIMD_FLAT : RT_WAVES_PER_S
     flush_stats(cx, nullptr, status);
 }
 
-template <bool FLAT>
+template <int FLAT>
 __global__ __launch_bounds__(256) void probe_kernel(const SceneDev S, const double* __restrict__ rays, unsigned n,
                                                     double* __restrict__ out, unsigned* __restrict__ status) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -465,6 +465,31 @@ int validate(const RtSceneDesc& d, uint32_t* flags_out) {
         if (nd.shape < 0 && k + 1 >= d.n_bvh_nodes) return RT_ERR_INVALID_SCENE;  // inner node needs a successor
     }
     if (d.world_bvh_root < -1 || d.world_bvh_root >= (int32_t)d.n_bvh_nodes) return RT_ERR_INVALID_SCENE;
+    if (d.world_bvh_root >= 0) {
+        // which nodes the world-level walk can reach, and whether one of their leaves names a shape that sits
+        // inside a group: the kernels then reach it through its ancestors (RT_CLASS_NESTED_LEAVES).  Such a
+        // leaf must be a primitive or a CSG node outside any CSG node (the direction index's contract).
+        std::vector<char> seen(d.n_bvh_nodes, 0);
+        std::vector<uint32_t> todo{(uint32_t)d.world_bvh_root};
+        while (!todo.empty()) {
+            const uint32_t k = todo.back();
+            todo.pop_back();
+            if (seen[k]) continue;
+            seen[k] = 1;
+            const RtBvhNode& nd = d.bvh_nodes[k];
+            if (nd.miss >= 0) todo.push_back((uint32_t)nd.miss);
+            if (nd.shape < 0) {
+                todo.push_back(k + 1);
+                continue;
+            }
+            const RtShape& leaf = d.shapes[nd.shape];
+            if (leaf.parent < 0) continue;
+            if (RT_KIND(leaf.kind_flags) == RT_GROUP) return RT_ERR_INVALID_SCENE;
+            for (int32_t a = leaf.parent; a >= 0; a = d.shapes[a].parent)
+                if (RT_KIND(d.shapes[a].kind_flags) == RT_CSG) return RT_ERR_INVALID_SCENE;
+            flags |= RT_SCENE_NESTED_LEAVES;
+        }
+    }
     if (d.world_bvh_root < 0) {
         bool flat = true;
         for (uint32_t i = 0; i < d.n_shapes; ++i) flat = flat && RT_KIND(d.shapes[i].kind_flags) <= RT_SMOOTH_TRIANGLE;
@@ -659,6 +684,7 @@ int launch_render(const RtScene* scene, const RtCameraDesc* cam, uint32_t depth,
     const dim3 grid((cam->hsize + 15u) / 16u, (rows.n_local_rows + 15u) / 16u);
     if (grid.y > 65535u * 16u) return RT_ERR_INVALID_ARG;
     const bool flat = (scene->dev.flags & RT_SCENE_FLAT) != 0;
+    const bool nested_leaves = (scene->dev.flags & RT_SCENE_NESTED_LEAVES) != 0;
     const bool staged = scene->dev.stage_bytes != 0;
     // the per-lane list area is read only by the containers walk and by shadow tests among shadowless
     // primitives: a scene with neither leaves the LDS to more resident blocks
@@ -692,11 +718,15 @@ int launch_render(const RtScene* scene, const RtCameraDesc* cam, uint32_t depth,
 #define RT_WF_PAIR(ST, FL, SG) wf_level_kernel<ST, FL, SG, true>, wf_level_kernel<ST, FL, SG, false>
         for (unsigned k = 0; k <= depth; ++k) {
             if (d_stats)
-                staged && flat ? level(RT_WF_PAIR(true, true, true), k)
-                       : (flat ? level(RT_WF_PAIR(true, true, false), k) : level(RT_WF_PAIR(true, false, false), k));
+                staged && flat ? level(RT_WF_PAIR(true, RT_CLASS_FLAT, true), k)
+                : flat         ? level(RT_WF_PAIR(true, RT_CLASS_FLAT, false), k)
+                : nested_leaves ? level(RT_WF_PAIR(true, RT_CLASS_NESTED_LEAVES, false), k)
+                               : level(RT_WF_PAIR(true, RT_CLASS_GENERAL, false), k);
             else
-                staged && flat ? level(RT_WF_PAIR(false, true, true), k)
-                       : (flat ? level(RT_WF_PAIR(false, true, false), k) : level(RT_WF_PAIR(false, false, false), k));
+                staged && flat ? level(RT_WF_PAIR(false, RT_CLASS_FLAT, true), k)
+                : flat         ? level(RT_WF_PAIR(false, RT_CLASS_FLAT, false), k)
+                : nested_leaves ? level(RT_WF_PAIR(false, RT_CLASS_NESTED_LEAVES, false), k)
+                               : level(RT_WF_PAIR(false, RT_CLASS_GENERAL, false), k);
             hipLaunchKernelGGL(wf_mark_kernel, dim3(1), dim3(RT_WF_SHARDS), 0, stream, ws, k);
         }
         for (unsigned k = depth; k-- > 0;)  // generation `depth` has no budget left and so no nodes
@@ -713,14 +743,17 @@ int launch_render(const RtScene* scene, const RtCameraDesc* cam, uint32_t depth,
     const bool dense = staged && flat && lds <= 53u * 1024u;
     auto pick = [&](auto stats_tag) {
         constexpr bool ST = decltype(stats_tag)::value;
-        if (!flat && staged) return opaque ? go(render_kernel<ST, false, true, false>) : go(render_kernel<ST, false, true, true>);
-        if (!flat) return opaque ? go(render_kernel<ST, false, false, false>) : go(render_kernel<ST, false, false, true>);
-        if (!staged) return opaque ? go(render_kernel<ST, true, false, false>) : go(render_kernel<ST, true, false, true>);
-        if (opaque) return dense ? go(render_kernel<ST, true, true, false, true>) : go(render_kernel<ST, true, true, false>);
+        constexpr int G = RT_CLASS_GENERAL, N = RT_CLASS_NESTED_LEAVES, F = RT_CLASS_FLAT;
+        if (!flat && nested_leaves && staged) return opaque ? go(render_kernel<ST, N, true, false>) : go(render_kernel<ST, N, true, true>);
+        if (!flat && nested_leaves) return opaque ? go(render_kernel<ST, N, false, false>) : go(render_kernel<ST, N, false, true>);
+        if (!flat && staged) return opaque ? go(render_kernel<ST, G, true, false>) : go(render_kernel<ST, G, true, true>);
+        if (!flat) return opaque ? go(render_kernel<ST, G, false, false>) : go(render_kernel<ST, G, false, true>);
+        if (!staged) return opaque ? go(render_kernel<ST, F, false, false>) : go(render_kernel<ST, F, false, true>);
+        if (opaque) return dense ? go(render_kernel<ST, F, true, false, true>) : go(render_kernel<ST, F, true, false>);
 #ifndef RT_DENSE_RECURSIVE
 #define RT_DENSE_RECURSIVE 1
 #endif
-        return dense && RT_DENSE_RECURSIVE ? go(render_kernel<ST, true, true, true, true>) : go(render_kernel<ST, true, true, true>);
+        return dense && RT_DENSE_RECURSIVE ? go(render_kernel<ST, F, true, true, true>) : go(render_kernel<ST, F, true, true>);
     };
     if (d_stats)
         pick(std::true_type{});
@@ -1048,11 +1081,14 @@ int rt_hip_color_at(const RtScene* scene, const double* rays, uint32_t n, uint32
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_out), (size_t)n * 3u * sizeof(double)));
         HIP_TRY(hipMemcpy(d_rays, rays, (size_t)n * 6u * sizeof(double), hipMemcpyHostToDevice));
         if (scene->dev.flags & RT_SCENE_FLAT)
-            hipLaunchKernelGGL(color_at_kernel<true>, dim3((n + 255u) / 256u), dim3(256), 0, nullptr, scene->dev, d_rays,
-                               n, (int)depth, d_out, scene->d_status);
+            hipLaunchKernelGGL(color_at_kernel<RT_CLASS_FLAT>, dim3((n + 255u) / 256u), dim3(256), 0, nullptr, scene->dev,
+                               d_rays, n, (int)depth, d_out, scene->d_status);
+        else if (scene->dev.flags & RT_SCENE_NESTED_LEAVES)
+            hipLaunchKernelGGL(color_at_kernel<RT_CLASS_NESTED_LEAVES>, dim3((n + 255u) / 256u), dim3(256), 0, nullptr,
+                               scene->dev, d_rays, n, (int)depth, d_out, scene->d_status);
         else
-            hipLaunchKernelGGL(color_at_kernel<false>, dim3((n + 255u) / 256u), dim3(256), 0, nullptr, scene->dev, d_rays,
-                               n, (int)depth, d_out, scene->d_status);
+            hipLaunchKernelGGL(color_at_kernel<RT_CLASS_GENERAL>, dim3((n + 255u) / 256u), dim3(256), 0, nullptr, scene->dev,
+                               d_rays, n, (int)depth, d_out, scene->d_status);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpy(out_rgb, d_out, (size_t)n * 3u * sizeof(double), hipMemcpyDeviceToHost));
         return read_status(scene, nullptr);
@@ -1072,11 +1108,14 @@ int rt_hip_probe(const RtScene* scene, const double* rays, uint32_t n, double* o
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_out), (size_t)n * 16u * sizeof(double)));
         HIP_TRY(hipMemcpy(d_rays, rays, (size_t)n * 6u * sizeof(double), hipMemcpyHostToDevice));
         if (scene->dev.flags & RT_SCENE_FLAT)
-            hipLaunchKernelGGL(probe_kernel<true>, dim3((n + 255u) / 256u), dim3(256), 0, nullptr, scene->dev, d_rays, n,
-                               d_out, scene->d_status);
+            hipLaunchKernelGGL(probe_kernel<RT_CLASS_FLAT>, dim3((n + 255u) / 256u), dim3(256), 0, nullptr, scene->dev, d_rays,
+                               n, d_out, scene->d_status);
+        else if (scene->dev.flags & RT_SCENE_NESTED_LEAVES)
+            hipLaunchKernelGGL(probe_kernel<RT_CLASS_NESTED_LEAVES>, dim3((n + 255u) / 256u), dim3(256), 0, nullptr, scene->dev,
+                               d_rays, n, d_out, scene->d_status);
         else
-            hipLaunchKernelGGL(probe_kernel<false>, dim3((n + 255u) / 256u), dim3(256), 0, nullptr, scene->dev, d_rays, n,
-                               d_out, scene->d_status);
+            hipLaunchKernelGGL(probe_kernel<RT_CLASS_GENERAL>, dim3((n + 255u) / 256u), dim3(256), 0, nullptr, scene->dev,
+                               d_rays, n, d_out, scene->d_status);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpy(out, d_out, (size_t)n * 16u * sizeof(double), hipMemcpyDeviceToHost));
         return read_status(scene, nullptr);

@@ -38,6 +38,7 @@ namespace rtd {
 #define RT_CONTAINERS_CAP RT_LIST_CAP
 #define RT_SCENE_HAS_SHADOWLESS 1u
 #define RT_SCENE_FLAT 2u  // primitives only at world level, no acceleration structure
+#define RT_SCENE_NESTED_LEAVES 16u  // the world-level hierarchy names shapes nested in groups directly (global hierarchy)
 #define RT_SCENE_RECURSIVE 4u  // some material reflects or transmits: color_at can recurse (world.rs:98-127)
 
 struct SceneDev {
@@ -81,12 +82,18 @@ enum {
 #define RT_STATUS_LIST_OVERFLOW (1u << 6)  // 1 << -RT_ERR_LIST_OVERFLOW
 #define RT_STATUS_NAN_T (1u << 7)          // 1 << -RT_ERR_NAN_T
 
-template <bool STATS, bool FLAT>
+// Scene class a kernel is instantiated for (the template parameter called FLAT for historical reasons):
+// what the traversal has to be able to do.
+enum { RT_CLASS_GENERAL = 0,        // groups / CSG, hierarchies per level
+       RT_CLASS_FLAT = 1,           // RT_SCENE_FLAT: plain primitives, no hierarchy at all
+       RT_CLASS_NESTED_LEAVES = 2   // general + RT_SCENE_NESTED_LEAVES
+};
+template <bool STATS, int FLAT>
 struct Ctx {
     unsigned cnt[STATS ? ST_COUNT : 1];
     unsigned status;
 };
-template <bool STATS, bool FLAT>
+template <bool STATS, int FLAT>
 RT_DEV void count(Ctx<STATS, FLAT>& cx, int what, unsigned n = 1) {
     if constexpr (STATS) cx.cnt[what] += n;
 }
@@ -203,7 +210,7 @@ RT_DEV T load_uniform(const T* p) {
 #endif
 }
 
-template <bool STATS, bool FLAT>
+template <bool STATS, int FLAT>
 RT_DEV void prim_intersect_rec(const double* __restrict__ inv, unsigned kf, const RtConic* __restrict__ conic,
                                const RtTriangle* __restrict__ tri, const Ray& parent_ray, PrimHits& h,
                                Ctx<STATS, FLAT>& cx) {
@@ -240,7 +247,7 @@ RT_DEV void prim_intersect_rec(const double* __restrict__ inv, unsigned kf, cons
     }
 }
 
-template <bool STATS, bool FLAT>
+template <bool STATS, int FLAT>
 RT_DEV void prim_intersect(const SceneDev& S, const RtShape* __restrict__ sh, unsigned kf, const Ray& parent_ray,
                            PrimHits& h, Ctx<STATS, FLAT>& cx) {
     // shape.rs:28-32, ahead of the branches: lanes holding different kinds of primitive share it
@@ -398,8 +405,30 @@ RT_DEV void cand_begin(const SceneDev& S, const Ray& ray, CandIter& it) {
         it.e = S.dir_cell_start[cell + 1];
     }
 }
+// The way down to a shape exactly as the nested traversal takes it: the ray through every ancestor's
+// transform, outermost first, and past every group's gate (compound.rs:93-95).  `r` = the ray in the
+// space of the shape's parent, `n` = the shape's nesting level; false when a gate turns the ray away.
+template <bool STATS, int FLAT>
+RT_DEV bool descend_to(const SceneDev& S, int parent, const Ray& world_ray, Ray& r, int& n, Ctx<STATS, FLAT>& cx) {
+    int chain[RT_STACK];
+    n = ancestor_chain(S, parent, chain);
+    r = world_ray;
+    bool reachable = true;
+    for (int q = n - 1; q >= 0 && reachable; --q) {
+        const RtShape* __restrict__ g = S.shapes + chain[q];
+        r = transform_ray(g->inv, r);
+        count(cx, ST_RAY_XFORM);
+        if (RT_KIND(g->kind_flags) == RT_GROUP) {
+            const RtGroup* __restrict__ gg = S.groups + g->param;
+            count(cx, ST_GATES);
+            reachable = gg->n_children != 0u && box_intersects(gg->bmin, gg->bmax, r);
+        }
+    }
+    return reachable;
+}
+
 // Next reachable candidate: its shape index (or -1 when exhausted), `r` = ray at its level `n`.
-template <bool STATS, bool FLAT>
+template <bool STATS, int FLAT>
 RT_DEV int cand_next(const SceneDev& S, const Ray& ray, CandIter& it, Ray& r, int& n, Ctx<STATS, FLAT>& cx) {
     const V3 d = ray.d;
     while (it.k < it.e) {
@@ -410,20 +439,7 @@ RT_DEV int cand_next(const SceneDev& S, const Ray& ray, CandIter& it, Ray& r, in
         if (!(fabs(a) <= c->thr)) continue;
         // walk down to the shape exactly as the traversal would: transforms and group gates
         const int node = (int)c->visit;
-        int chain[RT_STACK];
-        n = ancestor_chain(S, S.shapes[node].parent, chain);
-        r = ray;
-        bool reachable = true;
-        for (int q = n - 1; q >= 0 && reachable; --q) {
-            const RtShape* __restrict__ g = S.shapes + chain[q];
-            r = transform_ray(g->inv, r);
-            count(cx, ST_RAY_XFORM);
-            if (RT_KIND(g->kind_flags) == RT_GROUP) {
-                const RtGroup* __restrict__ gg = S.groups + g->param;
-                count(cx, ST_GATES);
-                reachable = gg->n_children != 0u && box_intersects(gg->bmin, gg->bmax, r);
-            }
-        }
+        const bool reachable = descend_to(S, S.shapes[node].parent, ray, r, n, cx);
         if (reachable) return node;
     }
     return -1;
@@ -440,7 +456,7 @@ RT_DEV int cand_next(const SceneDev& S, const Ray& ray, CandIter& it, Ray& r, in
 // through it (groups inside CSG nodes never carry one: see the flattener).
 // Shape::intersect / Compound::local_intersect / World::intersections
 // (shape.rs:28-32, compound.rs:87-117, world.rs:45-53).
-template <bool USE_BVH, bool STATS, bool FLAT, class SW>
+template <bool USE_BVH, bool STATS, int FLAT, class SW>
 RT_DEV int list_eval_core(const SceneDev& S, SW& W, int begin, int end, int level0, int base0, int top0,
                           double bound, Ctx<STATS, FLAT>& cx) {
     int level = level0;
@@ -457,6 +473,7 @@ RT_DEV int list_eval_core(const SceneDev& S, SW& W, int begin, int end, int leve
     bool bvh = false;
     int cur = 0, lend = 0;  // nothing at hand: the first pass through the loop picks a source
     bool started = false;
+    int resume = -2;  // >= -1: the world walk continues at this node once the pseudo level at hand is done
     V3 inv_d = v3(0.0, 0.0, 0.0);
     for (;;) {
         int s = -1;
@@ -482,6 +499,15 @@ RT_DEV int list_eval_core(const SceneDev& S, SW& W, int begin, int end, int leve
         }
         if (s < 0) {  // level exhausted
             if (level == floor) {
+                if (FLAT == RT_CLASS_NESTED_LEAVES && USE_BVH && resume >= -1) {  // back from a nested CSG node to the world walk
+                    level = floor = level0;
+                    ray = ray0;
+                    bvh = true;
+                    cur = resume;
+                    resume = -2;
+                    inv_d = v3(1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z);
+                    continue;
+                }
                 if (USE_BVH && in_cands) {  // next direction candidate, or on to the walk
                     int n;
                     Ray r;
@@ -526,6 +552,34 @@ RT_DEV int list_eval_core(const SceneDev& S, SW& W, int begin, int end, int leve
         const RtShape* __restrict__ sh = S.shapes + s;
         const unsigned kf = sh->kind_flags;
         const unsigned kind = RT_KIND(kf);
+        if (FLAT == RT_CLASS_NESTED_LEAVES && USE_BVH && level == level0 && floor == level0 && level0 == 0 &&
+            sh->parent >= 0 && kind != RT_GROUP) {
+            // a nested shape named directly by the world-level hierarchy (see trace): a primitive is met
+            // through its ancestors right here; a CSG node becomes a one-shape pseudo level, like a
+            // direction candidate, after which the walk picks up where it was
+            Ray at;
+            int n;
+            if (!descend_to(S, sh->parent, ray0, at, n, cx)) continue;
+            if (kind <= RT_SMOOTH_TRIANGLE) {
+                PrimHits h;
+                prim_intersect(S, sh, kf, at, h, cx);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (((h.keep >> k) & 1u) && h.t[k] <= bound) {
+                        top = list_insert(W, base, top, h.t[k], (uint32_t)s, cx.status);
+                        count(cx, ST_LIST_ENTRIES);
+                    }
+                }
+                continue;
+            }
+            resume = cur;
+            level = floor = n;
+            ray = at;
+            bvh = false;
+            cur = s;
+            lend = s + 1;
+            continue;
+        }
         if (kind <= RT_SMOOTH_TRIANGLE) {
             PrimHits h;
             prim_intersect(S, sh, kf, ray, h, cx);
@@ -568,7 +622,7 @@ RT_DEV int list_eval_core(const SceneDev& S, SW& W, int begin, int end, int leve
 }
 
 // A compound subtree evaluated on its own (CSG nodes met by the streaming traversal).
-template <bool STATS, bool FLAT, class SW>
+template <bool STATS, int FLAT, class SW>
 RT_DEV_COLD int list_eval(const SceneDev& S, SW& W, int begin, int end, int level0, int base0, double bound,
                      Ctx<STATS, FLAT>& cx) {
     return list_eval_core<false>(S, W, begin, end, level0, base0, base0, bound, cx);
@@ -603,7 +657,7 @@ RT_DEV bool accel_box(const RtBvhNode* __restrict__ nd, const V3& o, const V3& i
 // a primitive is intersected, a CSG node is materialised through list_eval; the surviving hits go
 // to the closest-hit reduction or, for a shadow feeler, to the "anything before the light" test.
 // Returns true when a shadow hit was found.
-template <bool STATS, bool FLAT, class SW>
+template <bool STATS, int FLAT, class SW>
 RT_DEV bool process_leaf(const SceneDev& S, SW& W, int s, const RtShape* __restrict__ sh, unsigned kf,
                          const Ray& ray, int level, bool shadow, double limit, Best& best, Ctx<STATS, FLAT>& cx) {
     if (RT_KIND(kf) <= RT_SMOOTH_TRIANGLE) {
@@ -637,10 +691,10 @@ RT_DEV bool process_leaf(const SceneDev& S, SW& W, int s, const RtShape* __restr
 }
 
 // World::intersections (world.rs:45-53) as a sorted list at W.lt/lid[0, n), cut at t <= bound.
-template <bool STATS, bool FLAT, class SW>
+template <bool STATS, int FLAT, class SW>
 RT_DEV int world_list(const SceneDev& S, SW& W, const Ray& ray, double bound, Ctx<STATS, FLAT>& cx) {
     int top = 0;
-    if constexpr (FLAT) {
+    if constexpr (FLAT == RT_CLASS_FLAT) {
         const int n = (int)S.n_shapes;
         for (int s = 0; s < n; ++s) {
             const RtShape rec = load_uniform(S.g_shapes + s);
@@ -671,10 +725,10 @@ RT_DEV int world_list(const SceneDev& S, SW& W, const Ray& ray, double bound, Ct
 // intersection.rs:154-158).  shadow == true: returns true as soon as a shadow-casting
 // primitive is met at 0 <= t < limit (world.rs:85-96).  Colour rays and shadow feelers share
 // this one loop so that the lanes of a wave stay together whatever each one is tracing.
-template <bool STATS, bool FLAT, class SW>
+template <bool STATS, int FLAT, class SW>
 RT_DEV bool trace(const SceneDev& S, SW& W, const Ray& world_ray, bool shadow, double limit, Best& best,
                   Ctx<STATS, FLAT>& cx) {
-    if constexpr (FLAT) {
+    if constexpr (FLAT == RT_CLASS_FLAT) {
         // only primitives, no acceleration structure: every lane walks the same shape sequence,
         // so the records are fetched once per wave through the scalar cache
         bool found = false;
@@ -777,7 +831,24 @@ RT_DEV bool trace(const SceneDev& S, SW& W, const Ray& world_ray, bool shadow, d
         const unsigned kf = sh->kind_flags;
         const unsigned kind = RT_KIND(kf);
         if (kind != RT_GROUP) {
-            if (process_leaf(S, W, s, sh, kf, ray, level, shadow, limit, best, cx)) return true;
+            // The world-level hierarchy may name a primitive (or CSG node) nested in groups directly: it is
+            // then reached the way the reference reaches it, through its ancestors' transforms and gates.
+            // (The loop's own ray and level stand in for the descended ones and are put back afterwards, so
+            // that the ordinary case carries nothing extra.)
+            const bool nested = FLAT == RT_CLASS_NESTED_LEAVES && level == 0 && sh->parent >= 0;
+            if (nested) {
+                Ray at;
+                int n;
+                if (!descend_to(S, sh->parent, world_ray, at, n, cx)) continue;
+                ray = at;
+                level = n;
+            }
+            const bool done = process_leaf(S, W, s, sh, kf, ray, level, shadow, limit, best, cx);
+            if (nested) {
+                ray = world_ray;
+                level = 0;
+            }
+            if (done) return true;
             continue;
         }
         const Ray lr = transform_ray(sh->inv, ray);
@@ -860,7 +931,7 @@ struct Comps {
 RT_DEV double containers_bound(double hit_t) { return hit_t + 1e-3 + fabs(hit_t) * 1e-9; }
 
 // The containers walk itself on the world list W.lt/lid[0, n).
-template <bool STATS, bool FLAT, class SW>
+template <bool STATS, int FLAT, class SW>
 RT_DEV void containers_walk(const SceneDev& S, SW& W, int n, double hit_t, double& n1, double& n2,
                             Ctx<STATS, FLAT>& cx) {
     int nc = 0;
@@ -888,7 +959,7 @@ RT_DEV void containers_walk(const SceneDev& S, SW& W, int n, double hit_t, doubl
     }
 }
 
-template <bool STATS, bool FLAT, class SW>
+template <bool STATS, int FLAT, class SW>
 RT_DEV void containers_pass(const SceneDev& S, SW& W, const Ray& world_ray, double hit_t, double& n1, double& n2,
                             Ctx<STATS, FLAT>& cx) {
     count(cx, ST_CONTAINER_PASSES);
@@ -896,14 +967,14 @@ RT_DEV void containers_pass(const SceneDev& S, SW& W, const Ray& world_ray, doub
     containers_walk(S, W, n, hit_t, n1, n2, cx);
 }
 
-template <bool STATS, bool FLAT, class SW>
+template <bool STATS, int FLAT, class SW>
 RT_DEV void prepare_computations(const SceneDev& S, SW& W, const Ray& ray, const Best& hit, bool want_n1n2,
                                  Comps& c, Ctx<STATS, FLAT>& cx) {
     count(cx, ST_HITS_SHADED);
     const RtShape* __restrict__ sh = S.shapes + hit.idx;
     const unsigned kind = RT_KIND(sh->kind_flags);
     int chain[RT_STACK];
-    const int n = FLAT ? 0 : ancestor_chain(S, sh->parent, chain);
+    const int n = FLAT == RT_CLASS_FLAT ? 0 : ancestor_chain(S, sh->parent, chain);
     count(cx, ST_NORMAL_LEVELS, 2u * (unsigned)(n + 1));
     const V3 point = ray.o + ray.d * hit.t;  // ray.rs:15-17
     c.idx = hit.idx;
@@ -940,7 +1011,7 @@ RT_DEV double schlick(const Comps& c) {  // intersection.rs:182-200
 }
 
 // World::is_shadowed (world.rs:85-96)
-template <bool STATS, bool FLAT, class SW>
+template <bool STATS, int FLAT, class SW>
 RT_DEV bool is_shadowed(const SceneDev& S, SW& W, V3 point, V3 light_position, Ctx<STATS, FLAT>& cx) {
     const V3 v = light_position - point;
     const double distance = magnitude(v);
@@ -962,7 +1033,7 @@ RT_DEV bool is_shadowed(const SceneDev& S, SW& W, V3 point, V3 light_position, C
 }
 
 // Primitive::lighting (primitive.rs:111-151); `color` is the material or pattern colour.
-template <bool STATS, bool FLAT>
+template <bool STATS, int FLAT>
 RT_DEV V3 lighting(const RtMaterial& m, V3 color, const RtLight& light, V3 position, V3 eye_v, V3 normal_v,
                    bool in_shadow, Ctx<STATS, FLAT>& cx) {
     count(cx, ST_LIGHTINGS);
@@ -1002,7 +1073,7 @@ RT_DEV V3 combine(V3 surface, V3 reflected, V3 refracted, bool use_schlick, doub
     return (surface + reflected) + refracted;
 }
 
-template <bool STATS, bool FLAT, class SW>
+template <bool STATS, int FLAT, class SW>
 RT_DEV bool find_hit(const SceneDev& S, SW& W, const Ray& ray, Best& best, Ctx<STATS, FLAT>& cx) {
     best.t = __builtin_inf();
     best.idx = -1;
@@ -1102,7 +1173,7 @@ struct Children {
     Ray refract_ray;
     double reflectance;
 };
-template <bool STATS, bool FLAT>
+template <bool STATS, int FLAT>
 RT_DEV void shade_children(const RtMaterial& m, const Shade& sd, const Ray& ray, int remaining, Children& ch,
                            Ctx<STATS, FLAT>& cx) {
     ch.do_reflect = !(m.reflective == 0.0 || remaining == 0);
@@ -1189,7 +1260,7 @@ RT_DEV bool wf_commit(const WfSpace& ws, unsigned shard, unsigned level, bool wa
 // splits into "lanes tracing shadows" and "lanes tracing colour rays".
 // `spill` (wave-front kernels): offered the children of the lane's FIRST shade_hit; when it takes
 // them, `deferred` is set and the returned colour means nothing.
-template <bool STATS, bool FLAT, class SW, class SP>
+template <bool STATS, int FLAT, class SW, class SP>
 RT_DEV V3 color_at(const SceneDev& S, SW& W, Frame* frames, Ray ray, int remaining, Ctx<STATS, FLAT>& cx, SP& spill,
                    bool& deferred, Shade& sd) {
     int sp = 0;
@@ -1352,7 +1423,7 @@ RT_DEV V3 color_at(const SceneDev& S, SW& W, Frame* frames, Ray ray, int remaini
     }
 }
 
-template <bool STATS, bool FLAT, class SW>
+template <bool STATS, int FLAT, class SW>
 RT_DEV V3 color_at(const SceneDev& S, SW& W, Frame* frames, Ray ray, int remaining, Ctx<STATS, FLAT>& cx) {
     NoSpill none;
     bool deferred = false;

@@ -314,6 +314,7 @@ RthFlat* rth_world_flatten(const RthWorld* w, int build_bvh) {
     return guard([&] {
         FlattenOptions opt;
         opt.build_bvh = build_bvh != 0;
+        opt.hierarchy = build_bvh >= 2 ? build_bvh - 1 : 0;  // 2: nested, 3: global
         auto* f = new RthFlat{flatten(w->w, opt), {}};
         f->desc = f->flat.desc();
         return f;

@@ -33,6 +33,10 @@ struct FlatScene {
 
 struct FlattenOptions {
     bool build_bvh = true;        // acceleration structures over group children / world shapes
+    // Which hierarchy: 0 = by policy; 1 = nested (one per large group level, entered through the group's
+    // gate); 2 = global (ONE hierarchy over every primitive / outermost CSG node of the world with boxes in
+    // world space; a leaf nested in groups is reached through its ancestors' transforms and gates)
+    int hierarchy = 0;
     size_t bvh_min_children = 8;  // groups smaller than this are scanned linearly
     uint32_t dir_res = 256;       // cube-map resolution of the direction index
 };

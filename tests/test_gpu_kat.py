@@ -108,21 +108,27 @@ def test_acceleration_structure_never_changes_the_image():
     world, cam = rt.synthetic(192, 108, 3000)
     cd = cam.desc()
     frames = []
-    for bvh in (False, True):
+    # none; the flattener's choice; one hierarchy per group level; one world-space hierarchy whose leaves
+    # are reached through their ancestors' transforms and gates
+    for bvh in (False, True, "nested", "global"):
         scene = rt.DeviceScene(world.flatten(build_bvh=bvh))
         buf = torch.zeros((108, 192, 3), dtype=torch.float64, device="cuda")
         scene.render_rows(cd, 5, 0, 1, 108, 108, buf.data_ptr())
         torch.cuda.synchronize()
         scene.status()
         frames.append(buf.cpu().numpy())
-    assert np.array_equal(frames[0], frames[1])
-    world, cam = rt.exercise("teapot", 160, 90)
-    a = cam.render(world).pixels
-    scene = rt.DeviceScene(world.flatten(build_bvh=False))
-    buf = torch.zeros((90, 160, 3), dtype=torch.float64, device="cuda")
-    scene.render_rows(cam.desc(), 5, 0, 1, 90, 90, buf.data_ptr())
-    torch.cuda.synchronize()
-    assert np.array_equal(a, buf.cpu().numpy())
+    for f in frames[1:]:
+        assert np.array_equal(frames[0], f)
+    for name in ("teapot", "csg", "hexagon"):  # large group; CSG nodes (with groups inside them); small groups
+        world, cam = rt.exercise(name, 160, 90)
+        a = cam.render(world).pixels
+        for bvh in (False, "nested", "global"):
+            scene = rt.DeviceScene(world.flatten(build_bvh=bvh))
+            buf = torch.zeros((90, 160, 3), dtype=torch.float64, device="cuda")
+            scene.render_rows(cam.desc(), 5, 0, 1, 90, 90, buf.data_ptr())
+            torch.cuda.synchronize()
+            scene.status()
+            assert np.array_equal(a, buf.cpu().numpy()), (name, bvh)
 
 
 def test_list_overflow_is_reported_not_hidden():
