@@ -316,6 +316,21 @@ int rt_hip_scene_status(const RtScene* scene, void* hip_stream);
 int rt_hip_color_at(const RtScene* scene, const double* rays, uint32_t n, uint32_t depth,
                     double* out_rgb);
 
+/* The per-pixel body of the reference's hand-rolled loops (exercises/shading.rs:44-57), which go
+ * round Camera::render and call the shape API themselves, over a batch of rays:
+ *     xs     = shape.intersect(&ray, &empty_trail)         shape.rs:28-32
+ *     hit    = xs.hit(None)                                intersection.rs:154-158
+ *     point  = ray.position(hit.t)                         ray.rs:15-17
+ *     normal = shape.normal_at(&point, ..)                 primitive.rs:153-192
+ *     colour = hit.shape.lighting(&point, &light, &-ray.direction, &normal, false, ..)   primitive.rs:111-151
+ * The scene stands for the shape (flatten a world holding just that shape: its
+ * World::intersections is shape.intersect with an empty trail); the scene's own lights are not
+ * used.  Unlike color_at there is no shadow test, the normal is NOT turned towards the eye, and
+ * the lighting is evaluated at `point` itself.  rays[n*6], out_rgb[n*3] (BLACK where nothing is
+ * hit), out_hit[n] = 1 where something is hit (may be NULL): HOST buffers.   */
+int rt_hip_shade_rays(const RtScene* scene, const RtLight* light, const double* rays, uint32_t n,
+                      double* out_rgb, uint8_t* out_hit);
+
 /* Debug/KAT probe of the first stage of color_at for a batch of rays (HOST
  * buffers): out[n*16] = { hit(0/1), t, shape index, n1, n2, inside(0/1),
  * point xyz(over_point), normal xyz, reflect xyz, is_shadowed(light 0) }.

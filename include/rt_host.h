@@ -96,6 +96,13 @@ void rth_world_free(RthWorld* w);
 /* World::color_at over a batch, ON THE GPU (world.rs:32). rays n*6, out n*3 (host). */
 int rth_world_color_at(const RthWorld* w, const double* rays, uint32_t n, uint32_t remaining, double* out_rgb);
 /* rt_hip_probe on this world (GPU). out n*16. */
+/* exercises/shading.rs:44-57 per ray for a batch, ON THE GPU (rt_hip_shade_rays): intersect, hit, normal_at and
+ * lighting of ONE shape as user code calls them.  light6 = position xyz, intensity rgb; rays n*6; out_rgb n*3;
+ * out_hit n (may be NULL). */
+int rth_shape_shade_rays(const RthShape* s, const double* light6, const double* rays, uint32_t n, double* out_rgb,
+                         uint8_t* out_hit);
+/* exercises/shading.rs:17-63 whole: out_rgb[500*500*3], pixels the sphere does not cover stay BLACK. */
+int rth_exercise_shading(double* out_rgb);
 int rth_world_probe(const RthWorld* w, const double* rays, uint32_t n, double* out);
 /* Object-tree description (transforms as given, nothing derived) for an independent checker.
  * Returns the number of doubles; writes at most `cap`. */

@@ -32,6 +32,7 @@ _sig("orc_render", C.c_int, _vp, C.c_int, C.c_int, C.c_double, _dp, C.c_int, C.c
      C.c_int, C.POINTER(C.c_uint64))
 _sig("orc_color_at", None, _vp, _dp, C.c_int, C.c_int, _dp)
 _sig("orc_probe", None, _vp, _dp, C.c_int, _dp)
+_sig("orc_shade_rays", None, _vp, _dp, _dp, C.c_int, _dp, C.POINTER(C.c_uint8))
 _sig("orc_intersect", C.c_int, _vp, _dp, _dp, C.POINTER(C.c_int), C.c_int)
 _sig("orc_normal_at", C.c_int, _vp, C.c_int, _dp, C.c_double, C.c_double, _dp)
 _sig("orc_is_shadowed", C.c_int, _vp, _dp, C.c_int)
@@ -99,6 +100,14 @@ class OracleWorld:
         out = np.empty((r.shape[0], 3))
         lib.orc_color_at(self._w, _p(r), r.shape[0], depth, _p(out))
         return out
+
+    def shade_rays(self, light6, rays):
+        """exercises/shading.rs:44-57 per ray -> (colours [n, 3], hit mask [n])."""
+        r = _arr(rays).reshape(-1, 6)
+        out = np.empty((r.shape[0], 3))
+        hit = np.zeros(r.shape[0], dtype=np.uint8)
+        lib.orc_shade_rays(self._w, _p(_arr(light6, 6)), _p(r), r.shape[0], _p(out), hit.ctypes.data_as(C.POINTER(C.c_uint8)))
+        return out, hit.astype(bool)
 
     def probe(self, rays):
         r = _arr(rays).reshape(-1, 6)

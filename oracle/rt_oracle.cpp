@@ -1122,6 +1122,29 @@ void orc_color_at(void* world, const double* rays, int n, int depth, double* out
     }
 }
 
+// The body of the hand-rolled pixel loop, exercises/shading.rs:44-57, per ray: all intersections, hit(None),
+// ray.position(t), the hit shape's normal_at, and its lighting at that point with in_shadow = false.  The world's
+// shapes stand for the shape the user code holds (a world of one shape intersects exactly like the shape).
+void orc_shade_rays(void* world, const double* light6, const double* rays, int n, double* out_rgb, uint8_t* out_hit) {
+    const World& w = *static_cast<World*>(world);
+    const Light light{v3(light6[0], light6[1], light6[2]), v3(light6[3], light6[4], light6[5])};
+    for (int i = 0; i < n; ++i) {
+        const double* r = rays + 6 * i;
+        const Ray ray{v3(r[0], r[1], r[2]), v3(r[3], r[4], r[5])};
+        out_rgb[3 * i] = out_rgb[3 * i + 1] = out_rgb[3 * i + 2] = 0.0;
+        out_hit[i] = 0;
+        const Intersections xs = world_intersections(w, ray);
+        const Intersection* hit = find_hit(xs, false);
+        if (!hit) continue;
+        const V3 point = ray_position(ray, hit->t);
+        const V3 normal = normal_at(*hit->shape, point, *hit);
+        const V3 eye = neg(ray.direction);
+        const V3 c = lighting(*hit->shape, point, light, eye, normal, false, hit->trail);
+        out_rgb[3 * i] = c.x, out_rgb[3 * i + 1] = c.y, out_rgb[3 * i + 2] = c.z;
+        out_hit[i] = 1;
+    }
+}
+
 // out[n*16] = hit, t, shape id, n1, n2, inside, over_point xyz, normal xyz, reflect xyz, is_shadowed(light 0)
 void orc_probe(void* world, const double* rays, int n, double* out) {
     const World& w = *static_cast<World*>(world);

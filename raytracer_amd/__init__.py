@@ -5,4 +5,4 @@ Rendering happens only in the HIP kernels of csrc/; importing fails if they are 
 """
 from ._native import RenderError, RtCameraDesc, RtSceneDesc, RtStats  # noqa: F401
 from .api import (Camera, Canvas, Compound, Conic, DeviceScene, FlatScene, Material, Matrix, Operation,  # noqa: F401
-                  Pattern, PointLight, Primitive, Shape, World, EXERCISES, exercise, obj, synthetic)
+                  Pattern, PointLight, Primitive, Shape, World, EXERCISES, exercise, exercise_shading, obj, synthetic)

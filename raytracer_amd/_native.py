@@ -144,7 +144,7 @@ class RthCamera(C.Structure):
 # Every symbol include/rt_hip.h declares (checked by tests/test_capi_symbols.py).
 HIP_SYMBOLS = ["rt_hip_init", "rt_hip_shutdown", "rt_hip_strerror", "rt_hip_last_hip_error", "rt_hip_scene_create",
                "rt_hip_scene_destroy", "rt_hip_scene_render", "rt_hip_scene_render_rgb8", "rt_hip_scene_set_wavefront", "rt_hip_scene_status", "rt_hip_render", "rt_hip_render_rgb8", "rt_hip_render_rows",
-               "rt_hip_color_at",
+               "rt_hip_color_at", "rt_hip_shade_rays",
                "rt_hip_probe", "rt_hip_quantize"]
 
 _vp = C.c_void_p
@@ -175,6 +175,7 @@ _sig(hip, "rt_hip_scene_render_rgb8", C.c_int, _vp, C.POINTER(RtCameraDesc), C.c
 _sig(hip, "rt_hip_render_rows", C.c_int, _vp, C.POINTER(RtCameraDesc), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
      C.c_uint32, _vp, _vp, _vp)
 _sig(hip, "rt_hip_color_at", C.c_int, _vp, c_double_p, C.c_uint32, C.c_uint32, c_double_p)
+_sig(hip, "rt_hip_shade_rays", C.c_int, _vp, C.POINTER(RtLight), c_double_p, C.c_uint32, c_double_p, C.POINTER(C.c_uint8))
 _sig(hip, "rt_hip_probe", C.c_int, _vp, c_double_p, C.c_uint32, c_double_p)
 _sig(hip, "rt_hip_quantize", C.c_int, _vp, C.c_uint64, _vp, _vp)
 
@@ -228,6 +229,8 @@ _sig(host, "rth_world_default", _vp)
 _sig(host, "rth_world_free", None, _vp)
 _sig(host, "rth_world_color_at", C.c_int, _vp, c_double_p, C.c_uint32, C.c_uint32, c_double_p)
 _sig(host, "rth_world_probe", C.c_int, _vp, c_double_p, C.c_uint32, c_double_p)
+_sig(host, "rth_shape_shade_rays", C.c_int, _vp, c_double_p, c_double_p, C.c_uint32, c_double_p, C.POINTER(C.c_uint8))
+_sig(host, "rth_exercise_shading", C.c_int, c_double_p)
 _sig(host, "rth_world_describe", C.c_size_t, _vp, c_double_p, C.c_size_t)
 _sig(host, "rth_camera_desc", C.c_int, C.POINTER(RthCamera), C.POINTER(RtCameraDesc))
 _sig(host, "rth_camera_render", C.c_int, C.POINTER(RthCamera), _vp, c_double_p, C.POINTER(RtStats))

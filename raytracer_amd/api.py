@@ -221,6 +221,17 @@ class Shape(_Handle):
         N.host.rth_shape_bounds(self._p, _dp(b))
         return b[:3].copy(), b[3:].copy()
 
+    def shade_rays(self, light, rays):
+        """exercises/shading.rs:44-57 per ray, on the GPU: `intersect` -> `hit` -> `normal_at` -> `lighting` of this
+        shape (no shadow test, normal as normal_at returns it).  rays [n, 6] -> (colours [n, 3], hit mask [n])."""
+        r = np.ascontiguousarray(np.asarray(rays, dtype=np.float64).reshape(-1, 6))
+        l = np.array(list(light.position) + list(light.intensity), dtype=np.float64)
+        out = np.zeros((r.shape[0], 3), dtype=np.float64)
+        hit = np.zeros(r.shape[0], dtype=np.uint8)
+        N.check(N.host.rth_shape_shade_rays(self._p, _dp(l), _dp(r), r.shape[0], _dp(out),
+                                            hit.ctypes.data_as(C.POINTER(C.c_uint8))), "shade_rays")
+        return out, hit.astype(bool)
+
     def children(self):
         return [Shape(N.host.rth_shape_child(self._p, i), "child") for i in range(N.host.rth_shape_num_children(self._p))]
 
@@ -432,6 +443,18 @@ class DeviceScene:
                 "rt_hip_scene_render_rgb8")
         return out
 
+    def shade_rays(self, light, rays):
+        """rt_hip_shade_rays on the resident scene (exercises/shading.rs:44-57 per ray) -> (colours [n, 3], hit mask [n])."""
+        r = np.ascontiguousarray(np.asarray(rays, dtype=np.float64).reshape(-1, 6))
+        l = N.RtLight()
+        l.position[:] = list(light.position)
+        l.intensity[:] = list(light.intensity)
+        out = np.zeros((r.shape[0], 3), dtype=np.float64)
+        hit = np.zeros(r.shape[0], dtype=np.uint8)
+        N.check(N.hip.rt_hip_shade_rays(self._p, C.byref(l), _dp(r), r.shape[0], _dp(out),
+                                        hit.ctypes.data_as(C.POINTER(C.c_uint8))), "rt_hip_shade_rays")
+        return out, hit.astype(bool)
+
     def set_wavefront(self, mode=-1, queue_items=0, node_items=0):
         """rt_hip_scene_set_wavefront: -1 by policy, 0 one launch, 1 one launch per generation of rays."""
         N.check(N.hip.rt_hip_scene_set_wavefront(self._p, mode, queue_items, node_items), "rt_hip_scene_set_wavefront")
@@ -526,3 +549,10 @@ def synthetic(width=7680, height=4320, n_primitives=10000, seed=0x5EED5EED):
     cam = N.RthCamera()
     N.check(N.host.rth_synthetic(width, height, n_primitives, seed, C.byref(w), C.byref(cam)), "synthetic")
     return World(_ptr=w.value), Camera._from_c(cam)
+
+
+def exercise_shading():
+    """exercises/shading.rs whole (its own 500 x 500 pixel loop over intersect / normal_at / lighting): Canvas."""
+    out = np.empty((500, 500, 3), dtype=np.float64)
+    N.check(N.host.rth_exercise_shading(_dp(out)), "exercise shading")
+    return Canvas(500, 500, out)

@@ -4,6 +4,7 @@
 //   render_kernel   Camera::render        (camera.rs:51-80)  8x8-pixel tile per wave
 //   color_at_kernel World::color_at       (world.rs:32-43)   batch of rays
 //   probe_kernel    prepare_computations  (intersection.rs:45-99) for the KATs
+//   shade_rays_kernel  intersect / hit / normal_at / lighting as user code calls them (exercises/shading.rs:44-57)
 //   quantize_kernel Canvas::scale_to_ppm_data (canvas.rs:85-90)
 // There is no CPU path in this library.
 #include <hip/hip_runtime.h>
@@ -302,6 +303,47 @@ __global__ __launch_bounds__(256) void probe_kernel(const SceneDev S, const doub
                 o[15] = is_shadowed(S, W, c.over_point, v3(l.position[0], l.position[1], l.position[2]), cx) ? 1.0 : 0.0;
             }
         }
+    }
+    flush_stats(cx, nullptr, status);
+}
+
+// exercises/shading.rs:44-57 per ray: closest hit of the scene, the hit shape's normal there and its
+// lighting at the point itself (no shadow test, normal not turned towards the eye).
+template <int FLAT>
+__global__ __launch_bounds__(256) void shade_rays_kernel(const SceneDev S, const RtLight light,
+                                                         const double* __restrict__ rays, unsigned n,
+                                                         double* __restrict__ out, uint8_t* __restrict__ out_hit,
+                                                         unsigned* __restrict__ status) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    Ctx<false, FLAT> cx;
+    cx.status = 0;
+    if (i < n) {
+        Scratch W;
+        const double* r = rays + (size_t)i * 6u;
+        const Ray ray{v3(r[0], r[1], r[2]), v3(r[3], r[4], r[5])};
+        V3 c = v3(0.0, 0.0, 0.0);
+        Best hit;
+        const bool found = find_hit(S, W, ray, hit, cx);
+        if (found) {
+            const RtShape* __restrict__ sh = S.shapes + hit.idx;
+            const unsigned kind = RT_KIND(sh->kind_flags);
+            int chain[RT_STACK];
+            const int nc = FLAT == RT_CLASS_FLAT ? 0 : ancestor_chain(S, sh->parent, chain);
+            const V3 point = ray.o + ray.d * hit.t;
+            const V3 local_point = world_to_object(S, sh, chain, nc, point);
+            const V3 normal = normal_to_world(S, sh, chain, nc, local_normal(S, sh, kind, local_point, chain, nc, ray));
+            const RtMaterial m = S.mats[sh->material];
+            V3 color = v3(m.color[0], m.color[1], m.color[2]);
+            if (m.pattern >= 0) {
+                unsigned nodes = 0;
+                color = pattern_eval(S.pats, m.pattern, local_point, nodes);
+            }
+            c = lighting(m, color, light, point, -ray.d, normal, false, cx);
+        }
+        out[(size_t)i * 3u] = c.x;
+        out[(size_t)i * 3u + 1u] = c.y;
+        out[(size_t)i * 3u + 2u] = c.z;
+        if (out_hit) out_hit[i] = found ? 1 : 0;
     }
     flush_stats(cx, nullptr, status);
 }
@@ -1096,6 +1138,39 @@ int rt_hip_color_at(const RtScene* scene, const double* rays, uint32_t n, uint32
     const int rc = body();
     if (d_rays) (void)hipFree(d_rays);
     if (d_out) (void)hipFree(d_out);
+    return rc;
+}
+
+int rt_hip_shade_rays(const RtScene* scene, const RtLight* light, const double* rays, uint32_t n, double* out_rgb,
+                      uint8_t* out_hit) {
+    if (!scene || !light || (n && (!rays || !out_rgb))) return RT_ERR_INVALID_ARG;
+    if (n == 0) return RT_OK;
+    double *d_rays = nullptr, *d_out = nullptr;
+    uint8_t* d_hit = nullptr;
+    auto body = [&]() -> int {
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_rays), (size_t)n * 6u * sizeof(double)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_out), (size_t)n * 3u * sizeof(double)));
+        if (out_hit) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_hit), (size_t)n));
+        HIP_TRY(hipMemcpy(d_rays, rays, (size_t)n * 6u * sizeof(double), hipMemcpyHostToDevice));
+        const dim3 grid((n + 255u) / 256u), block(256);
+        if (scene->dev.flags & RT_SCENE_FLAT)
+            hipLaunchKernelGGL(shade_rays_kernel<RT_CLASS_FLAT>, grid, block, 0, nullptr, scene->dev, *light, d_rays, n, d_out,
+                               d_hit, scene->d_status);
+        else if (scene->dev.flags & RT_SCENE_NESTED_LEAVES)
+            hipLaunchKernelGGL(shade_rays_kernel<RT_CLASS_NESTED_LEAVES>, grid, block, 0, nullptr, scene->dev, *light, d_rays,
+                               n, d_out, d_hit, scene->d_status);
+        else
+            hipLaunchKernelGGL(shade_rays_kernel<RT_CLASS_GENERAL>, grid, block, 0, nullptr, scene->dev, *light, d_rays, n,
+                               d_out, d_hit, scene->d_status);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpy(out_rgb, d_out, (size_t)n * 3u * sizeof(double), hipMemcpyDeviceToHost));
+        if (out_hit) HIP_TRY(hipMemcpy(out_hit, d_hit, (size_t)n, hipMemcpyDeviceToHost));
+        return read_status(scene, nullptr);
+    };
+    const int rc = body();
+    if (d_rays) (void)hipFree(d_rays);
+    if (d_out) (void)hipFree(d_out);
+    if (d_hit) (void)hipFree(d_hit);
     return rc;
 }
 

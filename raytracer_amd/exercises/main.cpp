@@ -14,7 +14,7 @@ int main(int argc, char** argv) {
     if (argc < 2) {
         std::fprintf(stderr, "usage: %s <exercise> [width height] [out.ppm] [resource_dir]\n  exercises:", argv[0]);
         for (const std::string& n : rt::exercise_names()) std::fprintf(stderr, " %s", n.c_str());
-        std::fprintf(stderr, "\n");
+        std::fprintf(stderr, " shading\n");
         return 2;
     }
     const std::string name = argv[1];
@@ -23,6 +23,12 @@ int main(int argc, char** argv) {
     const std::string out = argc > 4 ? argv[4] : name + ".ppm";
     const std::string resources = argc > 5 ? argv[5] : "tests/golden";
     try {
+        if (name == "shading") {  // exercises/shading.rs: its own pixel loop, 500 x 500
+            const std::string path = argc > 2 && argc != 4 ? argv[argc - 1] : out;
+            rt::shading_exercise().write_ppm(path);
+            std::printf("shading 500x500 written -> %s\n", path.c_str());
+            return 0;
+        }
         rt::Exercise e = rt::build_exercise(name, width, height, resources);
         const auto t0 = std::chrono::steady_clock::now();
         e.camera.render_to_file(e.world, out);  // camera.render(&world).write_ppm(path), quantised on the device

@@ -251,6 +251,25 @@ int rth_world_color_at(const RthWorld* w, const double* rays, uint32_t n, uint32
         return 0;
     });
 }
+int rth_shape_shade_rays(const RthShape* s, const double* light6, const double* rays, uint32_t n, double* out_rgb,
+                         uint8_t* out_hit) {
+    return guard_int([&] {
+        std::vector<Ray> rs(n);
+        std::memcpy(static_cast<void*>(rs.data()), rays, sizeof(double) * 6 * n);
+        const PointLight light(pt(light6), Color(light6[3], light6[4], light6[5]));
+        const ShadedRays out = shade_rays(s->s, light, rs);
+        std::memcpy(out_rgb, out.colors.data(), sizeof(double) * 3 * n);
+        if (out_hit) std::memcpy(out_hit, out.hit.data(), n);
+        return 0;
+    });
+}
+int rth_exercise_shading(double* out_rgb) {
+    return guard_int([&] {
+        const Canvas c = shading_exercise();
+        std::memcpy(out_rgb, c.pixels().data(), sizeof(double) * 3 * c.width() * c.height());
+        return 0;
+    });
+}
 int rth_world_probe(const RthWorld* w, const double* rays, uint32_t n, double* out) {
     return guard_int([&] {
         const FlatScene flat = flatten(w->w);

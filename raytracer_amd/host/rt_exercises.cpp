@@ -526,6 +526,36 @@ Exercise room(size_t w, size_t h) {
 
 }  // namespace
 
+// exercises/shading.rs:17-63
+Canvas shading_exercise() {
+    const size_t side_len = 500;
+    Canvas canvas = Canvas::empty(side_len, side_len);
+    const Point ray_origin(0.0, 0.0, -5.0);
+    const double wall_z = 10.0;
+    const double wall_size = 7.0;
+    const double pixel_size = wall_size / static_cast<double>(side_len);
+    const double half = wall_size / 2.0;
+    Material m;
+    m.color = Color(1.0, 0.2, 1.0);
+    const Shape sphere = Primitive::new_sphere().with_material(m).to_shape();
+    const PointLight light(Point(-10.0, 10.0, -10.0), Color::WHITE());
+    std::vector<Ray> rays;
+    rays.reserve(side_len * side_len);
+    for (size_t y = 0; y < side_len; ++y) {
+        const double world_y = half - pixel_size * static_cast<double>(y);
+        for (size_t x = 0; x < side_len; ++x) {
+            const double world_x = -half + pixel_size * static_cast<double>(x);
+            const Point position(world_x, world_y, wall_z);
+            rays.push_back(Ray{ray_origin, (position - ray_origin).normalize()});
+        }
+    }
+    const ShadedRays shaded = shade_rays(sphere, light, rays);  // :45-56 for every pixel at once
+    for (size_t y = 0; y < side_len; ++y)
+        for (size_t x = 0; x < side_len; ++x)
+            if (shaded.hit[y * side_len + x]) canvas.write_pixel(x, y, shaded.colors[y * side_len + x]);
+    return canvas;
+}
+
 const std::vector<std::string>& exercise_names() {
     static const std::vector<std::string> names = {"plane",  "scene", "pattern", "glass_bubble", "teapot",
                                                    "hexagon", "csg",   "cover",   "room",         "synthetic"};

@@ -21,6 +21,10 @@ const std::vector<std::string>& exercise_names();
 // for the "teapot" exercise; it is ignored otherwise.
 Exercise build_exercise(const std::string& name, size_t width, size_t height, const std::string& resource_dir);
 
+// exercises/shading.rs:17-63, the exercise that goes round Camera::render: a 500 x 500 canvas of one
+// sphere shaded by intersect / hit / normal_at / lighting per pixel (on the GPU: rt::shade_rays).
+Canvas shading_exercise();
+
 // Deterministic cover.rs/room.rs-style scene with `n_primitives` mixed primitives
 // in two levels of groups (SplitMix64, bit-reproducible).  BASELINE.json config 5
 // uses n_primitives = 10000, seed 0x5EED5EED.

@@ -73,6 +73,26 @@ std::vector<Color> World::color_at(const std::vector<Ray>& rays, uint8_t remaini
     return out;
 }
 
+ShadedRays shade_rays(const Shape& shape, const PointLight& light, const std::vector<Ray>& rays) {
+    // a world of just this shape: World::intersections (world.rs:45-53) is then shape.intersect with an empty trail
+    const FlatScene flat = flatten(World({shape}, {}));
+    const RtSceneDesc desc = flat.desc();
+    RtScene* scene = nullptr;
+    int rc = rt_hip_scene_create(&desc, &scene);
+    if (rc != RT_OK) fail(rc, "shade_rays");
+    RtLight l;
+    l.position[0] = light.position.x, l.position[1] = light.position.y, l.position[2] = light.position.z;
+    l.intensity[0] = light.intensity.red, l.intensity[1] = light.intensity.green, l.intensity[2] = light.intensity.blue;
+    ShadedRays out;
+    out.colors.resize(rays.size());
+    out.hit.resize(rays.size());
+    rc = rt_hip_shade_rays(scene, &l, reinterpret_cast<const double*>(rays.data()), static_cast<uint32_t>(rays.size()),
+                           reinterpret_cast<double*>(out.colors.data()), out.hit.data());
+    rt_hip_scene_destroy(scene);
+    if (rc != RT_OK) fail(rc, "shade_rays");
+    return out;
+}
+
 Color World::color_at(const Ray& ray, uint8_t remaining_recursions) const {
     return color_at(std::vector<Ray>{ray}, remaining_recursions)[0];
 }

@@ -255,6 +255,17 @@ struct Ray {  // reference: src/raytracer/ray.rs:5-8
     Vector direction;
 };
 
+// The reference's hand-rolled pixel loops (exercises/shading.rs:37-60) call the shape API per ray instead of
+// Camera::render:  xs = shape.intersect(&r, ..); hit = xs.hit(None); point = r.position(hit.t);
+// normal = shape.normal_at(&point, ..); colour = hit.shape.lighting(&point, &light, &-r.direction, &normal, false, ..)
+// (shape.rs:28, intersection.rs:154, ray.rs:15, primitive.rs:153, primitive.rs:111).  The same, for a batch of
+// rays, on the GPU (rt_hip_shade_rays): colors[i] is meaningful where hit[i] != 0 (BLACK elsewhere).
+struct ShadedRays {
+    std::vector<Color> colors;
+    std::vector<uint8_t> hit;
+};
+ShadedRays shade_rays(const Shape& shape, const PointLight& light, const std::vector<Ray>& rays);
+
 // ------------------------------------------------------------------- World ---
 // reference: src/raytracer/world.rs:17-43,130-145
 class World {
