@@ -18,9 +18,24 @@ acc = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.defaultdict(lambda: collections.defaultdict(int))
 for f in glob.glob(sys.argv[1] + "/pmc_*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
-        k = row["Kernel_Name"].split("(")[0][:60]
+        import re
+        m = re.search(r"\w+_kernel(<[^>]*>)?", row["Kernel_Name"])
+        k = m.group(0) if m else row["Kernel_Name"][:60]
         acc[k][row["Counter_Name"]] += float(row["Counter_Value"]); cnt[k][row["Counter_Name"]] += 1
 for k in acc:
+    a = acc[k]
+    if a.get("SQ_WAVES", 0) < 1000: continue
     print(k)
-    for c in sorted(acc[k]): print(f"  {c:34s} total {acc[k][c]:.6g}  dispatches {cnt[k][c]}")
+    for c in sorted(a): print(f"  {c:34s} total {a[c]:.6g}  dispatches {cnt[k][c]}")
+    d = lambda x, y: a[x] / a[y] if a.get(y) else float("nan")
+    print(f"  -> VALU lane utilisation       {d('SQ_THREAD_CYCLES_VALU', 'SQ_ACTIVE_INST_VALU') / 64:.3f}   (thread cycles / (active VALU cycles x 64))")
+    print(f"  -> waves waiting               {d('SQ_WAIT_ANY', 'SQ_WAVE_CYCLES'):.3f}   (SQ_WAIT_ANY / SQ_WAVE_CYCLES)")
+    print(f"  -> VALU issue share of a wave  {d('SQ_ACTIVE_INST_VALU', 'SQ_WAVE_CYCLES'):.3f}   (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES)")
+    print(f"  -> waves resident per SIMD     {d('SQ_WAVE_CYCLES', 'SQ_BUSY_CYCLES') / 4 * (a.get('SQ_BUSY_CYCLES', 0) and 1):.2f}   (SQ_WAVE_CYCLES / SQ_BUSY_CYCLES / 4 SIMDs; per-SE sampling, indicative)")
+    print(f"  -> VALU per SALU instruction   {d('SQ_INSTS_VALU', 'SQ_INSTS_SALU'):.2f}")
+    print(f"  -> VALU per vector memory read {d('SQ_INSTS_VALU', 'SQ_INSTS_VMEM_RD'):.1f}")
+    print(f"  -> L1 lines per read instr     {d('TCP_TOTAL_CACHE_ACCESSES_sum', 'SQ_INSTS_VMEM_RD'):.1f}")
+    print(f"  -> vector L1 miss share        {d('TCP_TCC_READ_REQ_sum', 'TCP_TOTAL_CACHE_ACCESSES_sum'):.3f}")
+    print(f"  -> L2 hit share                {d('TCC_HIT_sum', 'TCC_REQ_sum'):.3f}")
+    print(f"  -> TA busy share               {a.get('TA_TA_BUSY_sum', 0) / 256 / (a.get('GRBM_GUI_ACTIVE', 0) / 8) if a.get('GRBM_GUI_ACTIVE') else float('nan'):.3f}   (TA_TA_BUSY_sum / 256 TAs / (GRBM_GUI_ACTIVE / 8 XCDs))")
 PY
