@@ -7,7 +7,7 @@ for f in glob.glob(root + "/pmc_*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         name = row["Kernel_Name"]
         import re
-        m = re.search(r"render_kernel<[a-z, ]+>", name)
+        m = re.search(r"render_kernel<[a-z0-9, ]+>", name)
         k = m.group(0) if m else name[:40]
         acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k, cs in acc.items():
