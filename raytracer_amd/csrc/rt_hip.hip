@@ -127,6 +127,12 @@ __global__ __launch_bounds__(256, DENSE ? 3 : (FLAT == RT_CLASS_FLAT ? RT_WAVES_
     flush_stats(cx, stats, status);
 }
 
+#ifndef RT_WF_BLOCKS_SHIFT
+#define RT_WF_BLOCKS_SHIFT 2  // 2^2 neighbouring blocks of camera rays share a shard
+#endif
+#ifndef RT_WF_CHUNK_SHIFT
+#define RT_WF_CHUNK_SHIFT 9   // 2^9 consecutive items of a slice send their children to one shard
+#endif
 // One generation of colour rays (see "wave-front organisation" in rt_trace.h).  PRIMARY: generation
 // 0, rays from the camera, pixel tiles as in render_kernel.  Otherwise generation g > 0, rays from the
 // queue slices generation g - 1 filled, whose lengths only the device knows: block b strides over
@@ -165,7 +171,12 @@ __global__ __launch_bounds__(256, FLAT == RT_CLASS_FLAT ? RT_WAVES_PER_SIMD_FLAT
     typename std::conditional<STAGED && FLAT == RT_CLASS_FLAT, ScratchLds, Scratch>::type W;
     if constexpr (STAGED && FLAT == RT_CLASS_FLAT) W.attach(rt_lds + ((S_in.stage_bytes + 15u) & ~15u), threadIdx.x, S_in.lds_list_cap);
     Frame frames[RT_MAX_DEPTH + 1];
-    const unsigned out_shard = ((blockIdx.y * gridDim.x + blockIdx.x) * 4u + (threadIdx.x >> 6)) % RT_WF_SHARDS;  // per wave
+    // Where this wave's children go.  A shard's slice is read back in arrival order, 64 items to a wave, so
+    // what arrives together should belong together: four neighbouring blocks of camera rays (64 x 16 pixels),
+    // or eight consecutive 64-item chunks of a slice, share one shard -- picked by a hash, so that every shard
+    // sees the same load and few writers at a time.
+    unsigned out_shard = (((blockIdx.y * gridDim.x + blockIdx.x) >> RT_WF_BLOCKS_SHIFT) * 2654435761u) >> 24;
+    static_assert(RT_WF_SHARDS == 256, "the hash above keeps 8 bits");
     // One pass of one item: color_at up to the end of the lane's first shade_hit, then -- the wave
     // together -- its children into the next generation's queue, or its colour to whoever waits for it.
     // Returns false when the lane found no room and has to go again with `pending.open` cleared.
@@ -230,6 +241,7 @@ __global__ __launch_bounds__(256, FLAT == RT_CLASS_FLAT ? RT_WAVES_PER_SIMD_FLAT
         unsigned i = (blockIdx.x / RT_WF_SHARDS) * 256u + threadIdx.x;
         while (i < n_items) {
             const WfItem* it = q_in + i;
+            out_shard = ((in_shard + RT_WF_SHARDS * ((unsigned)__builtin_amdgcn_readfirstlane((int)i) >> RT_WF_CHUNK_SHIFT)) * 2654435761u) >> 24;
             if (pass(it->remaining != RT_WF_EMPTY, it->ray, (int)it->remaining, it->parent)) i += stride;
         }
     }
