@@ -1207,12 +1207,14 @@ RT_DEV bool wf_commit(const WfSpace& ws, unsigned shard, unsigned level, bool wa
                       int remaining_children) {
     const unsigned long long asking = __builtin_amdgcn_ballot_w64(want);
     if (asking == 0ull) return false;
-    const bool both = want && ch.do_reflect && ch.do_refract;
-    const unsigned long long two = __builtin_amdgcn_ballot_w64(both);
+    // the wave's reflected rays first, then its refracted ones: neighbours in the queue are traced together
+    const unsigned long long refl = __builtin_amdgcn_ballot_w64(want && ch.do_reflect);
+    const unsigned long long refr = __builtin_amdgcn_ballot_w64(want && ch.do_refract);
     const unsigned lane = __lane_id();
     const unsigned long long below = (1ull << lane) - 1ull;
     const unsigned n_nodes = (unsigned)__builtin_popcountll(asking);
-    const unsigned n_items = n_nodes + (unsigned)__builtin_popcountll(two);
+    const unsigned n_refl = (unsigned)__builtin_popcountll(refl);
+    const unsigned n_items = n_refl + (unsigned)__builtin_popcountll(refr);
     const int leader = __builtin_ctzll(__builtin_amdgcn_ballot_w64(true));
     unsigned long long base = 0ull;
     if ((int)lane == leader)
@@ -1223,16 +1225,17 @@ RT_DEV bool wf_commit(const WfSpace& ws, unsigned shard, unsigned level, bool wa
     // (a count past 2^32 would carry into the other half: with < 2^29 pixels, <= 63 colour rays per
     // pixel and 256 shards a shard is asked for fewer than 2^28 nodes)
     const unsigned rank = (unsigned)__builtin_popcountll(asking & below);
-    const unsigned kids = both ? 2u : 1u;
     const unsigned long long ni = (unsigned long long)ws.shards[shard].node_begin[level] + base_nodes + rank;
-    const unsigned long long qi = (unsigned long long)base_items + rank + (unsigned)__builtin_popcountll(two & below);
+    const unsigned long long q_refl = (unsigned long long)base_items + (unsigned)__builtin_popcountll(refl & below);
+    const unsigned long long q_refr = (unsigned long long)base_items + n_refl + (unsigned)__builtin_popcountll(refr & below);
     WfItem* __restrict__ q = ws.queue[(level + 1u) & 1u] + (size_t)shard * ws.q_cap;
     WfNode* __restrict__ nodes = ws.nodes + (size_t)shard * ws.node_cap;
-    if (!(ni < ws.node_cap && qi + kids <= ws.q_cap)) {
+    const bool fits_refl = !ch.do_reflect || q_refl < ws.q_cap, fits_refr = !ch.do_refract || q_refr < ws.q_cap;
+    if (!(ni < ws.node_cap && fits_refl && fits_refr)) {
         // no room: blank whatever part of the request did fit
         if (ni < ws.node_cap) nodes[ni].flags = WF_DEAD;
-        for (unsigned k = 0; k < kids; ++k)
-            if (qi + k < ws.q_cap) q[qi + k].remaining = RT_WF_EMPTY;
+        if (ch.do_reflect && q_refl < ws.q_cap) q[q_refl].remaining = RT_WF_EMPTY;
+        if (ch.do_refract && q_refr < ws.q_cap) q[q_refr].remaining = RT_WF_EMPTY;
         return false;
     }
     WfNode& n = nodes[ni];
@@ -1243,13 +1246,12 @@ RT_DEV bool wf_commit(const WfSpace& ws, unsigned shard, unsigned level, bool wa
     n.parent = parent;
     n.flags = (ch.use_schlick ? WF_USE_SCHLICK : 0u) | (ch.do_reflect ? WF_HAS_REFLECT : 0u) | (ch.do_refract ? WF_HAS_REFRACT : 0u);
     const uint32_t global_node = (uint32_t)((size_t)shard * ws.node_cap + ni);
-    unsigned at = (unsigned)qi;
     if (ch.do_reflect) {
-        WfItem& it = q[at++];
+        WfItem& it = q[q_refl];
         it.ray = Ray{reflect_o, reflect_d}, it.parent = global_node << 1, it.remaining = (uint32_t)remaining_children;
     }
     if (ch.do_refract) {
-        WfItem& it = q[at];
+        WfItem& it = q[q_refr];
         it.ray = ch.refract_ray, it.parent = (global_node << 1) | 1u, it.remaining = (uint32_t)remaining_children;
     }
     return true;
