@@ -164,8 +164,9 @@ typedef struct RtLight {
  * on box hit go to i+1, on miss go to `miss`.  Leaves name one child shape.
  * Boxes are padded outward so that no child the reference would hit is culled;
  * every accepted child is then tested with the reference's own arithmetic. */
-typedef struct RtBvhNode {
-    double bmin[3], bmax[3];
+typedef struct __attribute__((aligned(16))) RtBvhNode {
+    float bmin[3], bmax[3]; /* the padded f64 box rounded OUTWARD to f32: half the bytes per step of the walk; the
+                               test itself is done in f64 */
     int32_t miss;  /* next node when the box is missed (or after a leaf); -1 = end */
     int32_t shape; /* leaf: shape index, inner: -1 */
 } RtBvhNode;

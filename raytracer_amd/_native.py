@@ -85,7 +85,7 @@ class RtLight(C.Structure):
 
 
 class RtBvhNode(C.Structure):
-    _fields_ = [("bmin", C.c_double * 3), ("bmax", C.c_double * 3), ("miss", C.c_int32), ("shape", C.c_int32)]
+    _fields_ = [("bmin", C.c_float * 3), ("bmax", C.c_float * 3), ("miss", C.c_int32), ("shape", C.c_int32)]
 
 
 class RtDirCand(C.Structure):

@@ -351,10 +351,10 @@ RT_DEV int csg_filter(const SceneDev& S, SW& W, int b, int top, int g, unsigned 
 }
 
 // Acceleration-only slab test of the whole LINE against a padded box, cut at t <= bound.
-RT_DEV bool accel_line_box(const RtBvhNode* __restrict__ nd, const V3& o, const V3& inv_d, double bound) {
-    const double ax = (nd->bmin[0] - o.x) * inv_d.x, bx = (nd->bmax[0] - o.x) * inv_d.x;
-    const double ay = (nd->bmin[1] - o.y) * inv_d.y, by = (nd->bmax[1] - o.y) * inv_d.y;
-    const double az = (nd->bmin[2] - o.z) * inv_d.z, bz = (nd->bmax[2] - o.z) * inv_d.z;
+RT_DEV bool accel_line_box(const RtBvhNode& nd, const V3& o, const V3& inv_d, double bound) {
+    const double ax = ((double)nd.bmin[0] - o.x) * inv_d.x, bx = ((double)nd.bmax[0] - o.x) * inv_d.x;
+    const double ay = ((double)nd.bmin[1] - o.y) * inv_d.y, by = ((double)nd.bmax[1] - o.y) * inv_d.y;
+    const double az = ((double)nd.bmin[2] - o.z) * inv_d.z, bz = ((double)nd.bmax[2] - o.z) * inv_d.z;
     const double t0 = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmin(az, bz));
     const double t1 = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmax(az, bz));
     return !(t0 > t1) && !(t0 > bound);
@@ -479,10 +479,10 @@ RT_DEV int list_eval_core(const SceneDev& S, SW& W, int begin, int end, int leve
         int s = -1;
         if (USE_BVH && bvh) {
             while (cur >= 0) {
-                const RtBvhNode* __restrict__ nd = S.bvh + cur;
+                const RtBvhNode nd = S.bvh[cur];  // 32 bytes: two 16-byte reads
                 count(cx, ST_BVH_BOX);
-                const int miss = nd->miss;
-                const int leaf = nd->shape;
+                const int miss = nd.miss;
+                const int leaf = nd.shape;
                 if (!accel_line_box(nd, ray.o, inv_d, bound)) {
                     cur = miss;
                 } else if (leaf < 0) {
@@ -642,10 +642,10 @@ RT_DEV void offer(Best& best, double t, int idx) {  // first t >= 0; bit-equal t
 
 // Acceleration-only slab test against a padded box: can the ray meet it for some t in
 // [0, t_far]?  Never used for a decision the reference makes.
-RT_DEV bool accel_box(const RtBvhNode* __restrict__ nd, const V3& o, const V3& inv_d, double t_far) {
-    const double ax = (nd->bmin[0] - o.x) * inv_d.x, bx = (nd->bmax[0] - o.x) * inv_d.x;
-    const double ay = (nd->bmin[1] - o.y) * inv_d.y, by = (nd->bmax[1] - o.y) * inv_d.y;
-    const double az = (nd->bmin[2] - o.z) * inv_d.z, bz = (nd->bmax[2] - o.z) * inv_d.z;
+RT_DEV bool accel_box(const RtBvhNode& nd, const V3& o, const V3& inv_d, double t_far) {
+    const double ax = ((double)nd.bmin[0] - o.x) * inv_d.x, bx = ((double)nd.bmax[0] - o.x) * inv_d.x;
+    const double ay = ((double)nd.bmin[1] - o.y) * inv_d.y, by = ((double)nd.bmax[1] - o.y) * inv_d.y;
+    const double az = ((double)nd.bmin[2] - o.z) * inv_d.z, bz = ((double)nd.bmax[2] - o.z) * inv_d.z;
     const double t0 = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmin(az, bz));
     const double t1 = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmax(az, bz));
     // the reciprocal costs an ulp or two; boxes are padded far wider than that
@@ -775,10 +775,10 @@ RT_DEV bool trace(const SceneDev& S, SW& W, const Ray& world_ray, bool shadow, d
             // most of the wave active instead of once per lane per step
             const double t_far = shadow ? limit : best.t;
             while (cur >= 0) {
-                const RtBvhNode* __restrict__ nd = S.bvh + cur;
+                const RtBvhNode nd = S.bvh[cur];  // 32 bytes: two 16-byte reads
                 count(cx, ST_BVH_BOX);
-                const int miss = nd->miss;
-                const int leaf = nd->shape;
+                const int miss = nd.miss;
+                const int leaf = nd.shape;
                 if (!accel_box(nd, ray.o, inv_d, t_far)) {
                     cur = miss;
                 } else if (leaf < 0) {

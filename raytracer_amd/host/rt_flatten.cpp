@@ -112,6 +112,18 @@ ABox tight_box(const Shape& s, const Matrix4& to_target) {
     return b;
 }
 
+// f32 bounds that contain the f64 ones
+inline float round_down(double x) {
+    float f = static_cast<float>(x);
+    if (static_cast<double>(f) > x) f = std::nextafterf(f, -INFINITY);
+    return f;
+}
+inline float round_up(double x) {
+    float f = static_cast<float>(x);
+    if (static_cast<double>(f) < x) f = std::nextafterf(f, INFINITY);
+    return f;
+}
+
 struct BvhItem {
     ABox box;
     uint32_t shape;
@@ -127,7 +139,7 @@ void build_bvh_range(std::vector<BvhItem>& items, size_t lo, size_t hi, int32_t 
         cent.add(Point(items[i].box.centroid(0), items[i].box.centroid(1), items[i].box.centroid(2)));
     }
     RtBvhNode node;
-    for (int a = 0; a < 3; ++a) node.bmin[a] = all.mn[a], node.bmax[a] = all.mx[a];
+    for (int a = 0; a < 3; ++a) node.bmin[a] = round_down(all.mn[a]), node.bmax[a] = round_up(all.mx[a]);
     node.miss = after;
     if (n == 1) {
         node.shape = static_cast<int32_t>(items[lo].shape);
