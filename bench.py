@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--primitives", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--print-stats", action="store_true", help="event counters of one frame to stderr")
-    ap.add_argument("--hierarchy", default="auto", choices=["auto", "nested", "global"],
+    ap.add_argument("--hierarchy", default="auto", choices=["auto", "nested", "global", "none"],
                     help="acceleration structure: the flattener's policy, or one form forced (studies)")
     ap.add_argument("--depth", type=int, default=5, help="recursion budget (camera.rs:59 uses 5; other values are for studies)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle sample")
@@ -75,7 +75,7 @@ def main():
         world, cam = rt.synthetic(W, H, args.primitives)
     else:
         world, cam = rt.exercise(args.workload, W, H)
-    flat = world.flatten(build_bvh=True if args.hierarchy == "auto" else args.hierarchy)
+    flat = world.flatten(build_bvh={"auto": True, "none": False}.get(args.hierarchy, args.hierarchy))
     scene = rt.DeviceScene(flat)
     fd = flat.desc.contents
     scene_is_flat = fd.world_bvh_root < 0 and all((fd.shapes[i].kind_flags & 0xff) <= 6 for i in range(fd.n_shapes))

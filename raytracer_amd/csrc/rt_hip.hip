@@ -525,6 +525,7 @@ int validate(const RtSceneDesc& d, uint32_t* flags_out) {
         // leaf must be a primitive or a CSG node outside any CSG node (the direction index's contract).
         std::vector<char> seen(d.n_bvh_nodes, 0);
         std::vector<uint32_t> todo{(uint32_t)d.world_bvh_root};
+        bool has_group_leaf = false;  // a hierarchy with nested leaves names leaves only: its kernels never enter a group
         while (!todo.empty()) {
             const uint32_t k = todo.back();
             todo.pop_back();
@@ -537,12 +538,14 @@ int validate(const RtSceneDesc& d, uint32_t* flags_out) {
                 continue;
             }
             const RtShape& leaf = d.shapes[nd.shape];
+            if (RT_KIND(leaf.kind_flags) == RT_GROUP) has_group_leaf = true;
             if (leaf.parent < 0) continue;
             if (RT_KIND(leaf.kind_flags) == RT_GROUP) return RT_ERR_INVALID_SCENE;
             for (int32_t a = leaf.parent; a >= 0; a = d.shapes[a].parent)
                 if (RT_KIND(d.shapes[a].kind_flags) == RT_CSG) return RT_ERR_INVALID_SCENE;
             flags |= RT_SCENE_NESTED_LEAVES;
         }
+        if ((flags & RT_SCENE_NESTED_LEAVES) && has_group_leaf) return RT_ERR_INVALID_SCENE;
     }
     if (d.world_bvh_root < 0) {
         bool flat = true;

@@ -819,6 +819,9 @@ RT_DEV bool trace(const SceneDev& S, SW& W, const Ray& world_ray, bool shadow, d
                 if (bvh) inv_d = v3(1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z);
                 continue;
             }
+            if constexpr (FLAT == RT_CLASS_NESTED_LEAVES) {
+                break;  // no level is ever entered (see below)
+            } else {
             --level;
             ray = W.rays[level];
             cur = W.cur[level];
@@ -826,6 +829,7 @@ RT_DEV bool trace(const SceneDev& S, SW& W, const Ray& world_ray, bool shadow, d
             bvh = end == -2;
             if (bvh) inv_d = v3(1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z);
             continue;
+            }
         }
         const RtShape* __restrict__ sh = S.shapes + s;
         const unsigned kf = sh->kind_flags;
@@ -851,6 +855,9 @@ RT_DEV bool trace(const SceneDev& S, SW& W, const Ray& world_ray, bool shadow, d
             if (done) return true;
             continue;
         }
+        // A scene whose world-level hierarchy names nested leaves names ONLY leaves (primitives and CSG nodes: checked
+        // when the scene is created), and so do the direction candidates: its walk never enters a group.
+        if constexpr (FLAT == RT_CLASS_NESTED_LEAVES) continue;
         const Ray lr = transform_ray(sh->inv, ray);
         const RtGroup* __restrict__ g = S.groups + sh->param;
         count(cx, ST_RAY_XFORM);
