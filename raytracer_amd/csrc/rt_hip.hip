@@ -235,12 +235,25 @@ __global__ __launch_bounds__(256, FLAT == RT_CLASS_FLAT ? RT_WAVES_PER_SIMD_FLAT
         }
     } else {
         const unsigned in_shard = blockIdx.x % RT_WF_SHARDS;
-        const unsigned n_items = wf_items_of(ws, in_shard, level);
+        // the shard's slice, octant by octant, as one sequence
+        const unsigned sub_cap = ws.q_cap / RT_WF_BINS;
+        unsigned upto[RT_WF_BINS];
+        unsigned n_items = 0;
+#pragma unroll
+        for (unsigned o = 0; o < RT_WF_BINS; ++o) {
+            const unsigned n = ws.shards[in_shard].items[level & 1u][o];
+            n_items += n < sub_cap ? n : sub_cap;
+            upto[o] = n_items;
+        }
         const unsigned stride = (gridDim.x / RT_WF_SHARDS) * 256u;
         const WfItem* q_in = ws.queue[level & 1u] + (size_t)in_shard * ws.q_cap;
         unsigned i = (blockIdx.x / RT_WF_SHARDS) * 256u + threadIdx.x;
         while (i < n_items) {
-            const WfItem* it = q_in + i;
+            unsigned o = 0, first = 0;
+#pragma unroll
+            for (unsigned b = 0; b + 1u < RT_WF_BINS; ++b)
+                if (i >= upto[b]) o = b + 1u, first = upto[b];
+            const WfItem* it = q_in + (size_t)o * sub_cap + (i - first);
             out_shard = ((in_shard + RT_WF_SHARDS * ((unsigned)__builtin_amdgcn_readfirstlane((int)i) >> RT_WF_CHUNK_SHIFT)) * 2654435761u) >> 24;
             if (pass(it->remaining != RT_WF_EMPTY, it->ray, (int)it->remaining, it->parent)) i += stride;
         }
@@ -251,8 +264,9 @@ __global__ __launch_bounds__(256, FLAT == RT_CLASS_FLAT ? RT_WAVES_PER_SIMD_FLAT
 // generation g is traced: its nodes end here, generation g + 1's begin
 __global__ void wf_mark_kernel(WfSpace ws, unsigned level) {
     WfShard& sh = ws.shards[threadIdx.x];
-    const unsigned long long end = (unsigned long long)sh.node_begin[level] + (sh.asked[level] & 0xffffffffull);
+    const unsigned long long end = (unsigned long long)sh.node_begin[level] + sh.nodes_asked[level];
     sh.node_begin[level + 1u] = end < ws.node_cap ? (unsigned)end : ws.node_cap;
+    for (unsigned o = 0; o < RT_WF_BINS; ++o) sh.items[level & 1u][o] = 0u;  // read by this generation; the one after next counts here
 }
 
 // shade_hit's last line for every node of generation g (world.rs:76-82), children first
@@ -713,6 +727,7 @@ int ensure_wavefront_space(const RtScene* scene, size_t pixels) {
     size_t q_cap = (q_items + RT_WF_SHARDS - 1) / RT_WF_SHARDS, node_cap = (node_items + RT_WF_SHARDS - 1) / RT_WF_SHARDS;
     if (!scene->wf_q_items && q_cap < 128) q_cap = 128;
     if (!scene->wf_node_items && node_cap < 64) node_cap = 64;
+    q_cap = (q_cap + RT_WF_BINS - 1) / RT_WF_BINS * RT_WF_BINS;  // a slice is split evenly over the direction octants
     if (node_cap * RT_WF_SHARDS >= 0x40000000ull || q_cap * RT_WF_SHARDS >= 0x80000000ull) return RT_ERR_INVALID_ARG;
     WfSpace w{};
     auto body = [&]() -> int {

@@ -1123,25 +1123,35 @@ static_assert(sizeof(WfItem) == 64 && sizeof(WfNode) == 128, "wave-front records
 enum { WF_USE_SCHLICK = 1u, WF_HAS_REFLECT = 2u, WF_HAS_REFRACT = 4u, WF_DEAD = 8u };
 #define RT_WF_LEVELS (RT_MAX_DEPTH + 2)
 #define RT_WF_SHARDS 256u
-struct WfShard {  // one cache line of counters
-    // asked of this shard while generation g was traced: nodes (low half), items of generation g + 1
-    // (high half); both may run past the capacity -- those requests were refused
-    unsigned long long asked[RT_WF_LEVELS];
+#ifndef RT_WF_BINS
+#define RT_WF_BINS 8u  // a shard's slice of the queue is split by the direction of the ray: 8 = octants, 24 = octant x dominant axis
+#endif
+struct WfShard {  // the counters of one shard
+    // asked of this shard while generation g was traced; may run past the capacity -- those requests were refused
+    unsigned nodes_asked[RT_WF_LEVELS];
     unsigned node_begin[RT_WF_LEVELS + 1];  // generation g's nodes are [node_begin[g], node_begin[g + 1]) of the shard's slice
-    unsigned pad;
+    // items asked per octant: [g & 1] is read by generation g while generation g + 1's requests count up in the other row
+    // (zeroed again once read: wf_mark_kernel)
+    unsigned items[2][RT_WF_BINS];
+    unsigned pad[(RT_WF_BINS > 8u ? 128 : 64) - 2 * RT_WF_LEVELS - 1 - 2 * RT_WF_BINS];
 };
-static_assert(sizeof(WfShard) == 128, "one shard per 128-byte line");
+static_assert(sizeof(WfShard) % 128 == 0, "a shard's counters have their 128-byte lines to themselves");
 struct WfSpace {
     WfItem* queue[2];  // generation g reads queue[g & 1] and appends to queue[(g + 1) & 1]
     WfNode* nodes;
     WfShard* shards;
     const RtCameraDesc* cam;   // the launch's camera record, for the rare lane that has to start over
-    unsigned q_cap, node_cap;  // per shard
+    unsigned q_cap, node_cap;  // per shard; q_cap is a multiple of RT_WF_BINS
 };
 
-RT_DEV unsigned wf_items_of(const WfSpace& ws, unsigned shard, unsigned level) {  // level >= 1
-    const unsigned n = (unsigned)(ws.shards[shard].asked[level - 1u] >> 32);
-    return n < ws.q_cap ? n : ws.q_cap;
+RT_DEV unsigned wf_octant(const V3& d) {
+    const unsigned oct = (d.x < 0.0 ? 1u : 0u) | (d.y < 0.0 ? 2u : 0u) | (d.z < 0.0 ? 4u : 0u);
+    if constexpr (RT_WF_BINS == 24u) {
+        const double ax = fabs(d.x), ay = fabs(d.y), az = fabs(d.z);
+        const unsigned axis = ax >= ay && ax >= az ? 0u : (ay >= az ? 1u : 2u);
+        return axis * 8u + oct;
+    }
+    return oct;
 }
 
 RT_DEV void wf_deliver(WfNode* __restrict__ nodes, double* __restrict__ out, uint32_t parent, V3 value) {
@@ -1214,35 +1224,55 @@ RT_DEV bool wf_commit(const WfSpace& ws, unsigned shard, unsigned level, bool wa
                       int remaining_children) {
     const unsigned long long asking = __builtin_amdgcn_ballot_w64(want);
     if (asking == 0ull) return false;
-    // the wave's reflected rays first, then its refracted ones: neighbours in the queue are traced together
-    const unsigned long long refl = __builtin_amdgcn_ballot_w64(want && ch.do_reflect);
-    const unsigned long long refr = __builtin_amdgcn_ballot_w64(want && ch.do_refract);
     const unsigned lane = __lane_id();
     const unsigned long long below = (1ull << lane) - 1ull;
-    const unsigned n_nodes = (unsigned)__builtin_popcountll(asking);
-    const unsigned n_refl = (unsigned)__builtin_popcountll(refl);
-    const unsigned n_items = n_refl + (unsigned)__builtin_popcountll(refr);
+    WfShard& sh = ws.shards[shard];
+    // one node per asking lane
     const int leader = __builtin_ctzll(__builtin_amdgcn_ballot_w64(true));
-    unsigned long long base = 0ull;
-    if ((int)lane == leader)
-        base = atomicAdd(&ws.shards[shard].asked[level], ((unsigned long long)n_items << 32) | n_nodes);
-    const unsigned base_nodes = (unsigned)__shfl((int)(unsigned)(base & 0xffffffffull), leader, 64);
-    const unsigned base_items = (unsigned)__shfl((int)(unsigned)(base >> 32), leader, 64);
+    unsigned base_nodes = 0u;
+    if ((int)lane == leader) base_nodes = atomicAdd(&sh.nodes_asked[level], (unsigned)__builtin_popcountll(asking));
+    base_nodes = (unsigned)__shfl((int)base_nodes, leader, 64);
+    const unsigned long long ni =
+        (unsigned long long)sh.node_begin[level] + base_nodes + (unsigned)__builtin_popcountll(asking & below);
+    // The rays go to the part of the shard's slice that belongs to the octant of their direction, the wave's
+    // reflected rays first, then its refracted ones: a slice is read back in order, 64 items to a wave, and rays
+    // that start near each other and point the same way walk the same part of the hierarchy.  One atomic per
+    // octant present in the wave.
+    const unsigned sub_cap = ws.q_cap / RT_WF_BINS;
+    unsigned slot[2] = {0u, 0u};
+    bool given[2] = {false, false};
+    bool fits = ni < ws.node_cap;
+#pragma unroll
+    for (int kind = 0; kind < 2; ++kind) {
+        const bool has = want && (kind == 0 ? ch.do_reflect : ch.do_refract);
+        const unsigned oct = wf_octant(kind == 0 ? reflect_d : ch.refract_ray.d);
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(has);
+        while (todo != 0ull) {
+            const int first = __builtin_ctzll(todo);
+            const unsigned o = (unsigned)__shfl((int)oct, first, 64);
+            const unsigned long long group = __builtin_amdgcn_ballot_w64(has && oct == o);
+            unsigned base = 0u;
+            if ((int)lane == first) base = atomicAdd(&sh.items[(level + 1u) & 1u][o], (unsigned)__builtin_popcountll(group));
+            base = (unsigned)__shfl((int)base, first, 64);
+            if (has && oct == o) {
+                const unsigned long long at = (unsigned long long)base + (unsigned)__builtin_popcountll(group & below);
+                given[kind] = at < sub_cap;
+                if (given[kind])
+                    slot[kind] = o * sub_cap + (unsigned)at;
+                else
+                    fits = false;
+            }
+            todo &= ~group;
+        }
+    }
     if (!want) return false;
-    // (a count past 2^32 would carry into the other half: with < 2^29 pixels, <= 63 colour rays per
-    // pixel and 256 shards a shard is asked for fewer than 2^28 nodes)
-    const unsigned rank = (unsigned)__builtin_popcountll(asking & below);
-    const unsigned long long ni = (unsigned long long)ws.shards[shard].node_begin[level] + base_nodes + rank;
-    const unsigned long long q_refl = (unsigned long long)base_items + (unsigned)__builtin_popcountll(refl & below);
-    const unsigned long long q_refr = (unsigned long long)base_items + n_refl + (unsigned)__builtin_popcountll(refr & below);
     WfItem* __restrict__ q = ws.queue[(level + 1u) & 1u] + (size_t)shard * ws.q_cap;
     WfNode* __restrict__ nodes = ws.nodes + (size_t)shard * ws.node_cap;
-    const bool fits_refl = !ch.do_reflect || q_refl < ws.q_cap, fits_refr = !ch.do_refract || q_refr < ws.q_cap;
-    if (!(ni < ws.node_cap && fits_refl && fits_refr)) {
+    if (!fits) {
         // no room: blank whatever part of the request did fit
         if (ni < ws.node_cap) nodes[ni].flags = WF_DEAD;
-        if (ch.do_reflect && q_refl < ws.q_cap) q[q_refl].remaining = RT_WF_EMPTY;
-        if (ch.do_refract && q_refr < ws.q_cap) q[q_refr].remaining = RT_WF_EMPTY;
+        if (given[0]) q[slot[0]].remaining = RT_WF_EMPTY;
+        if (given[1]) q[slot[1]].remaining = RT_WF_EMPTY;
         return false;
     }
     WfNode& n = nodes[ni];
@@ -1254,11 +1284,11 @@ RT_DEV bool wf_commit(const WfSpace& ws, unsigned shard, unsigned level, bool wa
     n.flags = (ch.use_schlick ? WF_USE_SCHLICK : 0u) | (ch.do_reflect ? WF_HAS_REFLECT : 0u) | (ch.do_refract ? WF_HAS_REFRACT : 0u);
     const uint32_t global_node = (uint32_t)((size_t)shard * ws.node_cap + ni);
     if (ch.do_reflect) {
-        WfItem& it = q[q_refl];
+        WfItem& it = q[slot[0]];
         it.ray = Ray{reflect_o, reflect_d}, it.parent = global_node << 1, it.remaining = (uint32_t)remaining_children;
     }
     if (ch.do_refract) {
-        WfItem& it = q[q_refr];
+        WfItem& it = q[slot[1]];
         it.ray = ch.refract_ray, it.parent = (global_node << 1) | 1u, it.remaining = (uint32_t)remaining_children;
     }
     return true;
