@@ -32,6 +32,12 @@ using namespace rtd;
 #ifndef RT_WAVES_PER_SIMD_FLAT
 #define RT_WAVES_PER_SIMD_FLAT 2
 #endif
+#ifndef RT_WAVES_PER_SIMD_WF
+#define RT_WAVES_PER_SIMD_WF 3  // generation kernels of large scenes: incoherent rays wait on dependent reads, a third wave hides more of it than ~60 spilled VGPRs cost
+#endif
+#ifndef RT_WAVES_PER_SIMD_OPAQUE
+#define RT_WAVES_PER_SIMD_OPAQUE 3  // general kernels of scenes that cannot recurse (no frame stack, no n1/n2): 168 VGPRs, ~57 spilled, still faster
+#endif
 #ifndef RT_WAVES_PER_SIMD
 #define RT_WAVES_PER_SIMD 2  // register budget of the tracing kernels: 512 / this many VGPR+AGPR per lane
 #endif
@@ -73,7 +79,7 @@ extern __shared__ __align__(16) unsigned char rt_lds[];
 // blocks live on a CU.  Measured on pattern.rs (no recursion) at 2 / 3 / 4 waves/SIMD: 0.97 / 0.83 /
 // 1.02 ms; glass_bubble.rs 4.83 / 4.50 / -; the general kernel gains nothing (profiles/r01_variants.txt).
 template <bool STATS, int FLAT, bool STAGED, bool RECURSE = true, bool DENSE = false>
-__global__ __launch_bounds__(256, DENSE ? 3 : (FLAT == RT_CLASS_FLAT ? RT_WAVES_PER_SIMD_FLAT : RT_WAVES_PER_SIMD)) void render_kernel(const SceneDev S_in, RtCameraDesc cam, int depth, RowMap rows,
+__global__ __launch_bounds__(256, DENSE ? 3 : (FLAT == RT_CLASS_FLAT ? RT_WAVES_PER_SIMD_FLAT : (RECURSE ? RT_WAVES_PER_SIMD : RT_WAVES_PER_SIMD_OPAQUE))) void render_kernel(const SceneDev S_in, RtCameraDesc cam, int depth, RowMap rows,
                                                      double* __restrict__ out, RtStats* __restrict__ stats,
                                                      unsigned* __restrict__ status) {
     SceneDev S = S_in;
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(256, DENSE ? 3 : (FLAT == RT_CLASS_FLAT ? RT_WAVES_
 // (Nothing the cold no-room path needs is kept in registers across color_at: it re-reads its item,
 // or the camera record from the workspace.)
 template <bool STATS, int FLAT, bool STAGED, bool PRIMARY>
-__global__ __launch_bounds__(256, FLAT == RT_CLASS_FLAT ? RT_WAVES_PER_SIMD_FLAT : RT_WAVES_PER_SIMD) void wf_level_kernel(
+__global__ __launch_bounds__(256, FLAT == RT_CLASS_FLAT ? RT_WAVES_PER_SIMD_FLAT : RT_WAVES_PER_SIMD_WF) void wf_level_kernel(
     const SceneDev S_in, RtCameraDesc cam, int depth, RowMap rows, double* __restrict__ out, RtStats* __restrict__ stats,
     unsigned* __restrict__ status, WfSpace ws, unsigned level) {
     SceneDev S = S_in;
