@@ -35,6 +35,9 @@ using namespace rtd;
 #ifndef RT_WAVES_PER_SIMD_WF
 #define RT_WAVES_PER_SIMD_WF 3  // generation kernels of large scenes: incoherent rays wait on dependent reads, a third wave hides more of it than ~60 spilled VGPRs cost
 #endif
+#ifndef RT_WAVES_PER_SIMD_WF0
+#define RT_WAVES_PER_SIMD_WF0 3  // ... and the camera-ray generation
+#endif
 #ifndef RT_WAVES_PER_SIMD_OPAQUE
 #define RT_WAVES_PER_SIMD_OPAQUE 3  // general kernels of scenes that cannot recurse (no frame stack, no n1/n2): 168 VGPRs, ~57 spilled, still faster
 #endif
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(256, DENSE ? 3 : (FLAT == RT_CLASS_FLAT ? RT_WAVES_
 // (Nothing the cold no-room path needs is kept in registers across color_at: it re-reads its item,
 // or the camera record from the workspace.)
 template <bool STATS, int FLAT, bool STAGED, bool PRIMARY>
-__global__ __launch_bounds__(256, FLAT == RT_CLASS_FLAT ? RT_WAVES_PER_SIMD_FLAT : RT_WAVES_PER_SIMD_WF) void wf_level_kernel(
+__global__ __launch_bounds__(256, FLAT == RT_CLASS_FLAT ? RT_WAVES_PER_SIMD_FLAT : (PRIMARY ? RT_WAVES_PER_SIMD_WF0 : RT_WAVES_PER_SIMD_WF)) void wf_level_kernel(
     const SceneDev S_in, RtCameraDesc cam, int depth, RowMap rows, double* __restrict__ out, RtStats* __restrict__ stats,
     unsigned* __restrict__ status, WfSpace ws, unsigned level) {
     SceneDev S = S_in;
