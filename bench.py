@@ -81,7 +81,7 @@ def main():
     scene_is_flat = fd.world_bvh_root < 0 and all((fd.shapes[i].kind_flags & 0xff) <= 6 for i in range(fd.n_shapes))
     # the library's default policy (rt_hip.hip launch_render): large scenes that can recurse run one launch per generation of rays
     recursive = any(fd.materials[i].reflective != 0.0 or fd.materials[i].transparency != 0.0 for i in range(fd.n_materials))
-    generations = recursive and not scene_is_flat and fd.n_shapes >= 1024 and args.depth > 0
+    generations = recursive and not scene_is_flat and fd.n_shapes >= 192 and args.depth > 0
     cd = cam.desc()
     band = tiling.DEFAULT_BAND_ROWS
     n_parts = world_size

@@ -297,7 +297,7 @@ int rt_hip_render_rows(const RtScene* scene, const RtCameraDesc* cam, uint32_t d
  * either way, bit for bit.  mode 1: one launch per generation of rays -- a hit that needs reflected /
  * refracted colours parks itself in a node pool and queues its child rays, later launches fold the
  * children's colours back (dense waves at every depth); mode 0: one launch, every lane keeps the
- * whole ray tree of its pixel; mode -1 (default): the library chooses (mode 1 for scenes of >= 1024
+ * whole ray tree of its pixel; mode -1 (default): the library chooses (mode 1 for scenes of >= 192
  * shapes with an acceleration structure in which some material is reflective or transparent: the
  * generations cost ~400 B of queue traffic per ray, which small scenes do not earn back).  queue_items / node_items: capacities of one generation's ray queue
  * and of the node pool, 0 = default (2 and 3 per pixel of the frame); when they run out the affected

@@ -705,7 +705,7 @@ int read_status(const RtScene* scene, hipStream_t stream) {
 #define RT_WF_GRID 8192u  // blocks striding over a queue whose length only the device knows
 #endif
 #ifndef RT_WF_MIN_SHAPES
-#define RT_WF_MIN_SHAPES 1024u  // scenes below this stay with the one-launch kernel (see launch_render)
+#define RT_WF_MIN_SHAPES 192u  // scenes below this stay with the one-launch kernel (see launch_render): measured crossover ~165 shapes
 #endif
 #ifndef RT_WF_QUEUE_PER_PIXEL
 #define RT_WF_QUEUE_PER_PIXEL 2u  // queue slots per generation and node slots per frame, in units of the frame's pixels;
