@@ -248,7 +248,8 @@ def cpu_baseline(world, cam, args):
     rays = sum(counts)
     rows = len(range(0, H, stepr))
     return {"value": round(rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": f"every {stepr}th row of the same {cam.h_size}x{H} frame ({rows} rows, {rays} rays, {dt:.2f} s); "
+            "sample": (f"the whole {cam.h_size}x{H} frame" if stepr == 1 else f"every {stepr}th row of the same {cam.h_size}x{H} frame")
+                      + f" ({rows} rows, {rays} rays, {dt:.2f} s); "
                       "C++ restatement of the reference algorithm (oracle/), OpenMP schedule(dynamic,1) over rows"}
 
 
