@@ -31,7 +31,6 @@ for k in acc:
     print(f"  -> VALU lane utilisation       {d('SQ_THREAD_CYCLES_VALU', 'SQ_ACTIVE_INST_VALU') / 64:.3f}   (thread cycles / (active VALU cycles x 64))")
     print(f"  -> waves waiting               {d('SQ_WAIT_ANY', 'SQ_WAVE_CYCLES'):.3f}   (SQ_WAIT_ANY / SQ_WAVE_CYCLES)")
     print(f"  -> VALU issue share of a wave  {d('SQ_ACTIVE_INST_VALU', 'SQ_WAVE_CYCLES'):.3f}   (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES)")
-    print(f"  -> waves resident per SIMD     {d('SQ_WAVE_CYCLES', 'SQ_BUSY_CYCLES') / 4 * (a.get('SQ_BUSY_CYCLES', 0) and 1):.2f}   (SQ_WAVE_CYCLES / SQ_BUSY_CYCLES / 4 SIMDs; per-SE sampling, indicative)")
     print(f"  -> VALU per SALU instruction   {d('SQ_INSTS_VALU', 'SQ_INSTS_SALU'):.2f}")
     print(f"  -> VALU per vector memory read {d('SQ_INSTS_VALU', 'SQ_INSTS_VMEM_RD'):.1f}")
     print(f"  -> L1 lines per read instr     {d('TCP_TOTAL_CACHE_ACCESSES_sum', 'SQ_INSTS_VMEM_RD'):.1f}")
