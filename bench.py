@@ -63,12 +63,41 @@ def main():
         args.gpus = world_size
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    # Rehearsal on a box with fewer GPUs than ranks (RT_BENCH_REHEARSE=1): ranks share the devices there are and the
+    # collectives go through host memory over gloo.  Everything but the RCCL calls themselves runs as in the real job;
+    # the numbers of such a run mean nothing.
+    rehearse = os.environ.get("RT_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     N.check(N.hip.rt_hip_init(local_rank), "rt_hip_init")
     dev = torch.device("cuda", local_rank)
     if world_size > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+
+    def gather_shards(shard, gathered):
+        if not rehearse:
+            dist.gather(shard, gathered, dst=0)
+            return
+        torch.cuda.synchronize()
+        host = shard.cpu()
+        parts = [torch.empty_like(host) for _ in range(world_size)] if rank == 0 else None
+        dist.gather(host, parts, dst=0)
+        if rank == 0:
+            for g, h in zip(gathered, parts):
+                g.copy_(h)
+
+    def all_reduce(t, **kw):
+        if not rehearse:
+            dist.all_reduce(t, **kw)
+            return
+        h = t.cpu()
+        dist.all_reduce(h, **kw)
+        t.copy_(h)
 
     W, H = args.width, args.height
     if args.workload == "synthetic":
@@ -100,7 +129,7 @@ def main():
     def step():
         render()
         if n_parts > 1:
-            dist.gather(shard, gathered, dst=0)
+            gather_shards(shard, gathered)
             if rank == 0:
                 return gathered_all.index_select(0, perm)
         return shard
@@ -119,7 +148,7 @@ def main():
     my_flops = flops.algorithmic_flops(stats)
     tot = torch.tensor([my_rays, my_flops], dtype=torch.float64, device=dev)
     if n_parts > 1:
-        dist.all_reduce(tot)
+        all_reduce(tot)
     rays_per_frame, flops_per_frame = float(tot[0]), float(tot[1])
 
     for _ in range(args.warmup):
@@ -137,7 +166,7 @@ def main():
         render()
         ev[k][1].record()
         if n_parts > 1:
-            dist.gather(shard, gathered, dst=0)
+            gather_shards(shard, gathered)
             if rank == 0:
                 frame = gathered_all.index_select(0, perm)
     torch.cuda.synchronize()
@@ -163,7 +192,7 @@ def main():
 
     t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
     if n_parts > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, kernel_ms_max = float(t[0]), float(t[1])
 
     if rank == 0:
@@ -187,7 +216,8 @@ def main():
                 "workload": f"exercises/{args.workload}.rs" if args.workload != "synthetic"
                 else f"synthetic cover/room-style, {args.primitives} primitives, seed 0x5EED5EED",
                 "width": W, "height": H, "depth": args.depth, "band_rows": band,
-                "parallelism": f"row-bands x{n_parts}" + (" + RCCL gather to rank 0" if n_parts > 1 else ""),
+                "parallelism": f"row-bands x{n_parts}" + ((" + REHEARSAL (ranks share GPUs, gloo through host memory): timings meaningless"
+                                                        if rehearse else " + RCCL gather to rank 0") if n_parts > 1 else ""),
                 "rays_per_frame": int(rays_per_frame), "mpixels_per_s": round(W * H * args.steps / elapsed / 1e6, 3),
                 # per step: slowest rank's render launches (HIP events); the rest of the step = RCCL gather + row permutation
                 # on the root; and, outside the timed steps, one copy of the finished f64 frame to pinned host memory
