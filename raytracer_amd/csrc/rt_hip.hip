@@ -35,6 +35,9 @@ using namespace rtd;
 #ifndef RT_WAVES_PER_SIMD_WF
 #define RT_WAVES_PER_SIMD_WF 3  // generation kernels of large scenes: incoherent rays wait on dependent reads, a third wave hides more of it than ~60 spilled VGPRs cost
 #endif
+#ifndef RT_WAVES_PER_SIMD_DENSE_OPAQUE
+#define RT_WAVES_PER_SIMD_DENSE_OPAQUE 3  // staged flat scenes that cannot recurse
+#endif
 #ifndef RT_WAVES_PER_SIMD_WF0
 #define RT_WAVES_PER_SIMD_WF0 3  // ... and the camera-ray generation
 #endif
@@ -82,7 +85,7 @@ extern __shared__ __align__(16) unsigned char rt_lds[];
 // blocks live on a CU.  Measured on pattern.rs (no recursion) at 2 / 3 / 4 waves/SIMD: 0.97 / 0.83 /
 // 1.02 ms; glass_bubble.rs 4.83 / 4.50 / -; the general kernel gains nothing (profiles/r01_variants.txt).
 template <bool STATS, int FLAT, bool STAGED, bool RECURSE = true, bool DENSE = false>
-__global__ __launch_bounds__(256, DENSE ? 3 : (FLAT == RT_CLASS_FLAT ? RT_WAVES_PER_SIMD_FLAT : (RECURSE ? RT_WAVES_PER_SIMD : RT_WAVES_PER_SIMD_OPAQUE))) void render_kernel(const SceneDev S_in, RtCameraDesc cam, int depth, RowMap rows,
+__global__ __launch_bounds__(256, DENSE ? (RECURSE ? 3 : RT_WAVES_PER_SIMD_DENSE_OPAQUE) : (FLAT == RT_CLASS_FLAT ? RT_WAVES_PER_SIMD_FLAT : (RECURSE ? RT_WAVES_PER_SIMD : RT_WAVES_PER_SIMD_OPAQUE))) void render_kernel(const SceneDev S_in, RtCameraDesc cam, int depth, RowMap rows,
                                                      double* __restrict__ out, RtStats* __restrict__ stats,
                                                      unsigned* __restrict__ status) {
     SceneDev S = S_in;
