@@ -107,10 +107,12 @@ __global__ __launch_bounds__(256, DENSE ? (RECURSE ? 3 : RT_WAVES_PER_SIMD_DENSE
             S.tris = reinterpret_cast<const RtTriangle*>(rt_lds + S_in.stage_off[9]);
         }
     }
-    // 16x16 pixels per block, one 8x8 tile per wave: neighbouring pixels share a wave
+    // one 8x8 tile of pixels per wave (neighbouring pixels share a wave); a block is 1, 2x1 or 2x2 waves, as
+    // launched: the fewer, the sooner a CU gets new work (a block's slot is free only when its slowest wave is done)
     const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const unsigned x = blockIdx.x * 16u + (wave & 1u) * 8u + (lane & 7u);
-    const unsigned k = blockIdx.y * 16u + (wave >> 1) * 8u + (lane >> 3);
+    const unsigned wx = blockDim.x >= 128u ? 2u : 1u, wy = (blockDim.x >> 6) / wx;
+    const unsigned x = (blockIdx.x * wx + wave % wx) * 8u + (lane & 7u);
+    const unsigned k = (blockIdx.y * wy + wave / wx) * 8u + (lane >> 3);
     Ctx<STATS, FLAT> cx;
     cx.status = 0;
     if constexpr (STATS) {
@@ -774,8 +776,12 @@ int launch_render(const RtScene* scene, const RtCameraDesc* cam, uint32_t depth,
     // primitives: a scene with neither leaves the LDS to more resident blocks
     const bool opaque_scene = (scene->dev.flags & RT_SCENE_RECURSIVE) == 0;
     const bool needs_list = !opaque_scene || (scene->dev.flags & RT_SCENE_HAS_SHADOWLESS) != 0;
-    const unsigned lds = !staged ? 0u
-                         : ((scene->dev.stage_bytes + 15u) & ~15u) + (flat && needs_list ? RT_LDS_LIST_BYTES(scene->dev.lds_list_cap) : 0u);
+    auto lds_of = [&](unsigned threads) {
+        return !staged ? 0u
+                       : ((scene->dev.stage_bytes + 15u) & ~15u) +
+                             (flat && needs_list ? RT_LDS_LIST_BYTES(threads, scene->dev.lds_list_cap) : 0u);
+    };
+    const unsigned lds = lds_of(256u);  // the generation kernels run 256-thread blocks
     // Large scenes whose materials can spawn reflected / refracted rays are traced one generation of rays per
     // launch (dense waves at every depth); the others in one launch, each lane keeping its pixel.  The
     // generations cost ~400 B of queue and node traffic per colour ray, which only pays where a ray is
@@ -818,13 +824,31 @@ int launch_render(const RtScene* scene, const RtCameraDesc* cam, uint32_t depth,
         HIP_TRY(hipGetLastError());
         return RT_OK;
     }
+    const bool opaque = (scene->dev.flags & RT_SCENE_RECURSIVE) == 0;
+    // Block size: the smallest of 64 / 128 / 256 threads whose LDS share still lets the CU hold the waves the
+    // kernel's register budget allows (a block's slot is free only when its slowest wave is done: with one-wave
+    // blocks cover.rs -13 %, teapot.rs -11 %, csg.rs -9 %, glass_bubble.rs -6 % against four-wave blocks).
+    // DENSE (3 waves/SIMD) for staged flat scenes whenever some block size fits twelve waves' worth of LDS.
+    constexpr unsigned kLdsPerCu = 160u * 1024u;
+    auto fits = [&](unsigned threads, unsigned waves_per_simd) {
+        return (size_t)lds_of(threads) * (waves_per_simd * 4u * 64u / threads) <= kLdsPerCu;
+    };
+    const bool dense = staged && flat && (fits(64u, 3u) || fits(128u, 3u) || fits(256u, 3u));
+    const unsigned waves_per_simd = flat ? (staged && dense ? 3u : RT_WAVES_PER_SIMD_FLAT) : (opaque ? RT_WAVES_PER_SIMD_OPAQUE : RT_WAVES_PER_SIMD);
+    unsigned threads = 256u;
+    for (unsigned t : {64u, 128u})
+        if (fits(t, waves_per_simd)) {
+            threads = t;
+            break;
+        }
+    const unsigned wx = threads >= 128u ? 2u : 1u, wy = (threads / 64u) / wx;
+    const dim3 grid_r((cam->hsize + 8u * wx - 1u) / (8u * wx), (rows.n_local_rows + 8u * wy - 1u) / (8u * wy));
+    if (grid_r.y > 65535u) return RT_ERR_INVALID_ARG;
+    const unsigned lds_r = lds_of(threads);
     auto go = [&](auto kernel) {
-        hipLaunchKernelGGL(kernel, grid, block, lds, stream, scene->dev, *cam, (int)depth,
+        hipLaunchKernelGGL(kernel, grid_r, dim3(threads), lds_r, stream, scene->dev, *cam, (int)depth,
                            rows, d_out, d_stats, scene->d_status);
     };
-    const bool opaque = (scene->dev.flags & RT_SCENE_RECURSIVE) == 0;
-    // three blocks per CU need <= 160 KB / 3 of LDS each (and, unstaged, nothing says the denser variant pays)
-    const bool dense = staged && flat && lds <= 53u * 1024u;
     auto pick = [&](auto stats_tag) {
         constexpr bool ST = decltype(stats_tag)::value;
         constexpr int G = RT_CLASS_GENERAL, N = RT_CLASS_NESTED_LEAVES, F = RT_CLASS_FLAT;

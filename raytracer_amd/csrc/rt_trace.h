@@ -123,21 +123,24 @@ struct Scratch : LevelState {
 #ifndef RT_LDS_LIST_CAP
 #define RT_LDS_LIST_CAP 12
 #endif
-#define RT_LDS_LIST_BYTES(cap) (256u * (cap) * 16u)  // per 256-thread block and entry: t (8) + id (4) + container (4)
+#define RT_LDS_LIST_BYTES(threads, cap) ((threads) * (cap) * 16u)  // per block and entry: t (8) + id (4) + container (4)
 struct ScratchLds : LevelState {
     double* lt;
     uint32_t* lid;
     uint32_t* ct;
     int cap_;  // what this scene needs (<= RT_LDS_LIST_CAP): a shorter list leaves LDS to more resident blocks
+    int nt_;   // threads of the block (64, 128 or 256): the stride between a lane's entries
     RT_DEV void attach(unsigned char* block_base, unsigned tid, unsigned cap) {
+        const unsigned nt = blockDim.x;
         lt = reinterpret_cast<double*>(block_base) + tid;
-        lid = reinterpret_cast<uint32_t*>(block_base + 256u * cap * 8u) + tid;
-        ct = reinterpret_cast<uint32_t*>(block_base + 256u * cap * 12u) + tid;
+        lid = reinterpret_cast<uint32_t*>(block_base + nt * cap * 8u) + tid;
+        ct = reinterpret_cast<uint32_t*>(block_base + nt * cap * 12u) + tid;
         cap_ = (int)cap;
+        nt_ = (int)nt;
     }
-    RT_DEV double& LT(int i) { return lt[i * 256]; }
-    RT_DEV uint32_t& LID(int i) { return lid[i * 256]; }
-    RT_DEV uint32_t& CT(int i) { return ct[i * 256]; }
+    RT_DEV double& LT(int i) { return lt[i * nt_]; }
+    RT_DEV uint32_t& LID(int i) { return lid[i * nt_]; }
+    RT_DEV uint32_t& CT(int i) { return ct[i * nt_]; }
     RT_DEV int cap() const { return cap_; }
 };
 
