@@ -259,9 +259,9 @@ __global__ __launch_bounds__(256, FLAT == RT_CLASS_FLAT ? RT_WAVES_PER_SIMD_FLAT
             n_items += n < sub_cap ? n : sub_cap;
             upto[o] = n_items;
         }
-        const unsigned stride = (gridDim.x / RT_WF_SHARDS) * 256u;
+        const unsigned stride = (gridDim.x / RT_WF_SHARDS) * blockDim.x;
         const WfItem* q_in = ws.queue[level & 1u] + (size_t)in_shard * ws.q_cap;
-        unsigned i = (blockIdx.x / RT_WF_SHARDS) * 256u + threadIdx.x;
+        unsigned i = (blockIdx.x / RT_WF_SHARDS) * blockDim.x + threadIdx.x;
         while (i < n_items) {
             unsigned o = 0, first = 0;
 #pragma unroll
@@ -802,8 +802,9 @@ int launch_render(const RtScene* scene, const RtCameraDesc* cam, uint32_t depth,
                 hipLaunchKernelGGL(primary, grid, block, lds, stream, scene->dev, *cam, (int)depth, rows, d_out, d_stats,
                                    scene->d_status, ws, k);
             else
-                hipLaunchKernelGGL(later, dim3(RT_WF_GRID), block, lds, stream, scene->dev, *cam, (int)depth, rows, d_out,
-                                   d_stats, scene->d_status, ws, k);
+                // (one-wave blocks where nothing is staged: a block's slot is free only when its slowest wave is done)
+                hipLaunchKernelGGL(later, dim3(staged ? RT_WF_GRID : RT_WF_GRID * 4u), staged ? block : dim3(64), lds, stream,
+                                   scene->dev, *cam, (int)depth, rows, d_out, d_stats, scene->d_status, ws, k);
         };
 #define RT_WF_PAIR(ST, FL, SG) wf_level_kernel<ST, FL, SG, true>, wf_level_kernel<ST, FL, SG, false>
         for (unsigned k = 0; k <= depth; ++k) {
