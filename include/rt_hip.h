@@ -287,24 +287,38 @@ int rt_hip_scene_render_rgb8(const RtScene* scene, const RtCameraDesc* cam, uint
  * rows >= vsize are skipped.  part=0,n_parts=1 renders rows [0,n_local_rows).
  * d_out_rgb holds n_local_rows*hsize*3 doubles, local-row-major.
  * Row tiles are how the path shards across GPUs (camera.rs:52-54 treats rows as
- * independent rayon tasks).  If `d_stats` (device pointer to one RtStats,
+ * independent rayon tasks).  *cam is read before the call returns.  The call only enqueues work,
+ * except that the FIRST launch of a large scene at a given size allocates the wave-front workspace
+ * (rt_hip_scene_set_wavefront) and, when that has to grow, waits for the device first.  If `d_stats` (device pointer to one RtStats,
  * zeroed by the caller) is non-NULL the counting variant of the kernel runs. */
 int rt_hip_render_rows(const RtScene* scene, const RtCameraDesc* cam, uint32_t depth, uint32_t part,
                        uint32_t n_parts, uint32_t band_rows, uint32_t n_local_rows,
                        double* d_out_rgb, void* hip_stream, RtStats* d_stats);
 
 /* How launches on this scene organise color_at's recursion (world.rs:98-127); the image is the same
- * either way, bit for bit.  mode 1: one launch per generation of rays -- a hit that needs reflected /
- * refracted colours parks itself in a node pool and queues its child rays, later launches fold the
- * children's colours back (dense waves at every depth); mode 0: one launch, every lane keeps the
- * whole ray tree of its pixel; mode -1 (default): the library chooses (mode 1 for scenes of >= 192
- * shapes with an acceleration structure in which some material is reflective or transparent: the
- * generations cost ~400 B of queue traffic per ray, which small scenes do not earn back).  queue_items / node_items: capacities of one generation's ray queue
- * and of the node pool, 0 = default (2 and 3 per pixel of the frame); when they run out the affected
- * hits fall back to mode-0 behaviour.  The workspace (64 B per queue item, two queues; 128 B per
- * node) belongs to the scene and is allocated by the first launch that needs it.
+ * either way, bit for bit.  mode 0: one launch, every lane keeps the whole ray tree of its pixel.
+ * mode 1: one launch per generation of rays -- a hit that needs reflected / refracted colours parks
+ * itself in a node pool and queues its child rays, later launches fold the children's colours back
+ * (dense waves at every depth).  mode 2: a pipeline of kernels per generation -- traversal (closest
+ * hit, shadow feelers) in kernels of its own with persistent waves over a 4-wide hierarchy, shading
+ * in between; for scenes with a world-level hierarchy over primitives, no CSG node and no shadowless
+ * primitive (others are rendered as in mode 1).  mode -1 (default): the library chooses -- mode 2, else
+ * mode 1, for scenes of >= 192 shapes with an acceleration structure in which some material is
+ * reflective or transparent (the generations cost a few hundred bytes of queue traffic per ray, which
+ * small scenes do not earn back), mode 0 otherwise.  queue_items / node_items: capacities of one
+ * generation's ray queue and of the node pool, 0 = defaults in proportion to the pixels rendered at a
+ * time; when they run out the affected hits keep their subtrees to themselves (mode-0 behaviour:
+ * slower, same result).  The workspace belongs to the scene and is allocated -- with a device
+ * synchronisation when it has to grow -- by the first launch that needs it: mode 1 about 640 B per
+ * pixel of the frame; mode 2 about 460 B per pixel, at most ~4.5 GB (RT_HIP_WF_BUDGET_MB in the
+ * environment): larger frames are rendered in batches of rows.  If it cannot be allocated the
+ * launch falls back to mode 0.
  * Replaces: nothing in the reference (tuning). */
 int rt_hip_scene_set_wavefront(RtScene* scene, int mode, uint64_t queue_items, uint64_t node_items);
+
+/* Which kernels a render of this scene with recursion budget `depth` runs under the mode in force (a static
+ * string; for reports such as bench.py's roofline line).  Replaces: nothing in the reference. */
+const char* rt_hip_scene_kernels(const RtScene* scene, uint32_t depth);
 
 /* Run-time conditions raised by launches on this scene since the last call (RT_ERR_LIST_OVERFLOW,
  * RT_ERR_NAN_T) or RT_OK; synchronises `hip_stream` and clears them.  The blocking entry points

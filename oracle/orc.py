@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_PATH = os.path.join(_HERE, "librt_oracle.so")
+# RT_ORACLE_LIB: another build of the same source (bench.py's -O3 -march=native timing leg)
+_PATH = os.environ.get("RT_ORACLE_LIB") or os.path.join(_HERE, "librt_oracle.so")
 if not os.path.exists(_PATH):
     raise ImportError(f"{_PATH} is missing: run `make -C oracle`")
 lib = C.CDLL(_PATH)

@@ -455,8 +455,12 @@ class DeviceScene:
                                         hit.ctypes.data_as(C.POINTER(C.c_uint8))), "rt_hip_shade_rays")
         return out, hit.astype(bool)
 
+    def pipeline_name(self, depth=5):
+        """rt_hip_scene_kernels: which kernels a render of this scene runs."""
+        return N.hip.rt_hip_scene_kernels(self._p, depth).decode()
+
     def set_wavefront(self, mode=-1, queue_items=0, node_items=0):
-        """rt_hip_scene_set_wavefront: -1 by policy, 0 one launch, 1 one launch per generation of rays."""
+        """rt_hip_scene_set_wavefront: -1 by policy, 0 one launch, 1 one launch per generation of rays, 2 the kernel pipeline."""
         N.check(N.hip.rt_hip_scene_set_wavefront(self._p, mode, queue_items, node_items), "rt_hip_scene_set_wavefront")
 
     def status(self, stream=None):

@@ -1,11 +1,5 @@
-// rt_hip.hip -- gfx950 kernels and the C ABI of include/rt_hip.h.
-//
-// Kernels (one lane = one pixel or one ray, FP64, no FMA contraction):
-//   render_kernel   Camera::render        (camera.rs:51-80)  8x8-pixel tile per wave
-//   color_at_kernel World::color_at       (world.rs:32-43)   batch of rays
-//   probe_kernel    prepare_computations  (intersection.rs:45-99) for the KATs
-//   shade_rays_kernel  intersect / hit / normal_at / lighting as user code calls them (exercises/shading.rs:44-57)
-//   quantize_kernel Canvas::scale_to_ppm_data (canvas.rs:85-90)
+// rt_hip.hip -- host side and C ABI of include/rt_hip.h: scene validation and upload, kernel selection and launch.
+// The tracing kernels are in rt_kernels.h (instantiated by rt_inst.hip); the small bookkeeping kernels are here.
 // There is no CPU path in this library.
 #include <hip/hip_runtime.h>
 
@@ -19,260 +13,15 @@
 #include <type_traits>
 #include <vector>
 
-#include "rt_trace.h"
+#include "rt_host_internal.h"
 
 using namespace rtd;
+using namespace rtk;
 
-#ifndef RT_STAGE_MAX_BYTES
-#define RT_STAGE_MAX_BYTES 16384u  // table image; with the 48 KB LDS list the block stays within 64 KB of dynamic LDS
-#endif
-#ifndef RT_STAGE_MAX_BYTES_COMPOUND
-#define RT_STAGE_MAX_BYTES_COMPOUND 49152u  // scenes with groups / CSG (their lists stay in private memory): two blocks per CU keep 80 KB each
-#endif
-#ifndef RT_WAVES_PER_SIMD_FLAT
-#define RT_WAVES_PER_SIMD_FLAT 2
-#endif
-#ifndef RT_WAVES_PER_SIMD_WF
-#define RT_WAVES_PER_SIMD_WF 3  // generation kernels of large scenes: incoherent rays wait on dependent reads, a third wave hides more of it than ~60 spilled VGPRs cost
-#endif
-#ifndef RT_WAVES_PER_SIMD_DENSE_OPAQUE
-#define RT_WAVES_PER_SIMD_DENSE_OPAQUE 3  // staged flat scenes that cannot recurse
-#endif
-#ifndef RT_WAVES_PER_SIMD_WF0
-#define RT_WAVES_PER_SIMD_WF0 3  // ... and the camera-ray generation
-#endif
-#ifndef RT_WAVES_PER_SIMD_OPAQUE
-#define RT_WAVES_PER_SIMD_OPAQUE 3  // general kernels of scenes that cannot recurse (no frame stack, no n1/n2): 168 VGPRs, ~57 spilled, still faster
-#endif
-#ifndef RT_WAVES_PER_SIMD
-#define RT_WAVES_PER_SIMD 2  // register budget of the tracing kernels: 512 / this many VGPR+AGPR per lane
-#endif
-
-// ============================================================== kernels ===
 namespace {
 
-struct RowMap {  // local row k -> image row (rt_hip_render_rows)
-    uint32_t part, n_parts, band_rows, n_local_rows;
-};
-
-template <bool STATS, int FLAT>
-__device__ void flush_stats(Ctx<STATS, FLAT>& cx, RtStats* __restrict__ stats, unsigned* __restrict__ status) {
-    if (cx.status) atomicOr(status, cx.status);
-    if constexpr (STATS) {
-        unsigned long long* out = reinterpret_cast<unsigned long long*>(stats);
-#pragma unroll
-        for (int i = 0; i < ST_COUNT; ++i) {
-            unsigned v = cx.cnt[i];
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-            if ((threadIdx.x & 63u) == 0u && v) atomicAdd(out + i, (unsigned long long)v);
-        }
-    }
-}
-
-// FLAT: the scene holds only primitives and no acceleration structure (RT_SCENE_FLAT); that
-// variant carries none of the group / CSG / BVH machinery and so needs far fewer registers.
-//
-// STAGED (FLAT scenes whose tables fit RT_STAGE_MAX_BYTES): the block first copies the packed
-// table image into LDS and shades out of that copy; the per-lane, dependent record reads of
-// prepare_computations / lighting / pattern evaluation then cost an LDS access, not an L2 one.
-extern __shared__ __align__(16) unsigned char rt_lds[];
-
-// RECURSE == false: no material of the scene reflects or transmits (world.rs:99,110 always take their
-// early exits), so the kernel is instantiated with a recursion budget of zero: no frames, no n1 / n2,
-// and under_point / reflect_v / the containers walk fall away as dead code.
-// DENSE: 3 waves/SIMD (168 VGPRs, a few spilled) instead of 2 -- FLAT scenes whose LDS share lets three
-// blocks live on a CU.  Measured on pattern.rs (no recursion) at 2 / 3 / 4 waves/SIMD: 0.97 / 0.83 /
-// 1.02 ms; glass_bubble.rs 4.83 / 4.50 / -; the general kernel gains nothing (profiles/r01_variants.txt).
-template <bool STATS, int FLAT, bool STAGED, bool RECURSE = true, bool DENSE = false>
-__global__ __launch_bounds__(256, DENSE ? (RECURSE ? 3 : RT_WAVES_PER_SIMD_DENSE_OPAQUE) : (FLAT == RT_CLASS_FLAT ? RT_WAVES_PER_SIMD_FLAT : (RECURSE ? RT_WAVES_PER_SIMD : RT_WAVES_PER_SIMD_OPAQUE))) void render_kernel(const SceneDev S_in, RtCameraDesc cam, int depth, RowMap rows,
-                                                     double* __restrict__ out, RtStats* __restrict__ stats,
-                                                     unsigned* __restrict__ status) {
-    SceneDev S = S_in;
-    if constexpr (STAGED) {
-        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(S_in.stage);
-        uint4* dst = reinterpret_cast<uint4*>(rt_lds);
-        for (unsigned i = threadIdx.x; i < S_in.stage_bytes / 16u; i += blockDim.x) dst[i] = src[i];
-        __syncthreads();
-        S.shapes = reinterpret_cast<const RtShape*>(rt_lds + S_in.stage_off[0]);
-        S.conics = reinterpret_cast<const RtConic*>(rt_lds + S_in.stage_off[1]);
-        S.mats = reinterpret_cast<const RtMaterial*>(rt_lds + S_in.stage_off[2]);
-        S.pats = reinterpret_cast<const RtPattern*>(rt_lds + S_in.stage_off[3]);
-        S.lights = reinterpret_cast<const RtLight*>(rt_lds + S_in.stage_off[4]);
-        if constexpr (FLAT != RT_CLASS_FLAT) {  // small scenes with compounds: the traversal's tables too
-            S.groups = reinterpret_cast<const RtGroup*>(rt_lds + S_in.stage_off[5]);
-            S.csgs = reinterpret_cast<const RtCsg*>(rt_lds + S_in.stage_off[6]);
-            S.lhit = reinterpret_cast<const uint8_t*>(rt_lds + S_in.stage_off[7]);
-            S.bvh = reinterpret_cast<const RtBvhNode*>(rt_lds + S_in.stage_off[8]);
-            S.tris = reinterpret_cast<const RtTriangle*>(rt_lds + S_in.stage_off[9]);
-        }
-    }
-    // one 8x8 tile of pixels per wave (neighbouring pixels share a wave); a block is 1, 2x1 or 2x2 waves, as
-    // launched: the fewer, the sooner a CU gets new work (a block's slot is free only when its slowest wave is done)
-    const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const unsigned wx = blockDim.x >= 128u ? 2u : 1u, wy = (blockDim.x >> 6) / wx;
-    const unsigned x = (blockIdx.x * wx + wave % wx) * 8u + (lane & 7u);
-    const unsigned k = (blockIdx.y * wy + wave / wx) * 8u + (lane >> 3);
-    Ctx<STATS, FLAT> cx;
-    cx.status = 0;
-    if constexpr (STATS) {
-#pragma unroll
-        for (int i = 0; i < ST_COUNT; ++i) cx.cnt[i] = 0;
-    }
-    bool active = x < cam.hsize && k < rows.n_local_rows;
-    unsigned y = 0;
-    if (active) {
-        y = ((k / rows.band_rows) * rows.n_parts + rows.part) * rows.band_rows + k % rows.band_rows;
-        active = y < cam.vsize;
-    }
-    if (active) {
-        // STAGED scenes are small enough for the per-lane sorted list to live in LDS too
-        typename std::conditional<STAGED && FLAT == RT_CLASS_FLAT, ScratchLds, Scratch>::type W;
-        if constexpr (STAGED && FLAT == RT_CLASS_FLAT) W.attach(rt_lds + ((S_in.stage_bytes + 15u) & ~15u), threadIdx.x, S_in.lds_list_cap);
-        Frame frames[RT_MAX_DEPTH + 1];
-        const Ray ray = ray_for_pixel(cam, x, y);
-        count(cx, ST_RAY_PRIMARY);
-        const V3 c = color_at(S, W, frames, ray, RECURSE ? depth : 0, cx);
-        double* o = out + ((size_t)k * cam.hsize + x) * 3u;
-        o[0] = c.x;
-        o[1] = c.y;
-        o[2] = c.z;
-    }
-    flush_stats(cx, stats, status);
-}
-
-#ifndef RT_WF_BLOCKS_SHIFT
-#define RT_WF_BLOCKS_SHIFT 2  // 2^2 neighbouring blocks of camera rays share a shard
-#endif
-#ifndef RT_WF_CHUNK_SHIFT
-#define RT_WF_CHUNK_SHIFT 9   // 2^9 consecutive items of a slice send their children to one shard
-#endif
-// One generation of colour rays (see "wave-front organisation" in rt_trace.h).  PRIMARY: generation
-// 0, rays from the camera, pixel tiles as in render_kernel.  Otherwise generation g > 0, rays from the
-// queue slices generation g - 1 filled, whose lengths only the device knows: block b strides over
-// slice b % RT_WF_SHARDS together with the other blocks of that slice.
-// (Nothing the cold no-room path needs is kept in registers across color_at: it re-reads its item,
-// or the camera record from the workspace.)
-template <bool STATS, int FLAT, bool STAGED, bool PRIMARY>
-__global__ __launch_bounds__(256, FLAT == RT_CLASS_FLAT ? RT_WAVES_PER_SIMD_FLAT : (PRIMARY ? RT_WAVES_PER_SIMD_WF0 : RT_WAVES_PER_SIMD_WF)) void wf_level_kernel(
-    const SceneDev S_in, RtCameraDesc cam, int depth, RowMap rows, double* __restrict__ out, RtStats* __restrict__ stats,
-    unsigned* __restrict__ status, WfSpace ws, unsigned level) {
-    SceneDev S = S_in;
-    if constexpr (STAGED) {
-        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(S_in.stage);
-        uint4* dst = reinterpret_cast<uint4*>(rt_lds);
-        for (unsigned i = threadIdx.x; i < S_in.stage_bytes / 16u; i += blockDim.x) dst[i] = src[i];
-        __syncthreads();
-        S.shapes = reinterpret_cast<const RtShape*>(rt_lds + S_in.stage_off[0]);
-        S.conics = reinterpret_cast<const RtConic*>(rt_lds + S_in.stage_off[1]);
-        S.mats = reinterpret_cast<const RtMaterial*>(rt_lds + S_in.stage_off[2]);
-        S.pats = reinterpret_cast<const RtPattern*>(rt_lds + S_in.stage_off[3]);
-        S.lights = reinterpret_cast<const RtLight*>(rt_lds + S_in.stage_off[4]);
-        if constexpr (FLAT != RT_CLASS_FLAT) {  // small scenes with compounds: the traversal's tables too
-            S.groups = reinterpret_cast<const RtGroup*>(rt_lds + S_in.stage_off[5]);
-            S.csgs = reinterpret_cast<const RtCsg*>(rt_lds + S_in.stage_off[6]);
-            S.lhit = reinterpret_cast<const uint8_t*>(rt_lds + S_in.stage_off[7]);
-            S.bvh = reinterpret_cast<const RtBvhNode*>(rt_lds + S_in.stage_off[8]);
-            S.tris = reinterpret_cast<const RtTriangle*>(rt_lds + S_in.stage_off[9]);
-        }
-    }
-    Ctx<STATS, FLAT> cx;
-    cx.status = 0;
-    if constexpr (STATS) {
-#pragma unroll
-        for (int i = 0; i < ST_COUNT; ++i) cx.cnt[i] = 0;
-    }
-    typename std::conditional<STAGED && FLAT == RT_CLASS_FLAT, ScratchLds, Scratch>::type W;
-    if constexpr (STAGED && FLAT == RT_CLASS_FLAT) W.attach(rt_lds + ((S_in.stage_bytes + 15u) & ~15u), threadIdx.x, S_in.lds_list_cap);
-    Frame frames[RT_MAX_DEPTH + 1];
-    // Where this wave's children go.  A shard's slice is read back in arrival order, 64 items to a wave, so
-    // what arrives together should belong together: four neighbouring blocks of camera rays (64 x 16 pixels),
-    // or eight consecutive 64-item chunks of a slice, share one shard -- picked by a hash, so that every shard
-    // sees the same load and few writers at a time.
-    unsigned out_shard = (((blockIdx.y * gridDim.x + blockIdx.x) >> RT_WF_BLOCKS_SHIFT) * 2654435761u) >> 24;
-    static_assert(RT_WF_SHARDS == 256, "the hash above keeps 8 bits");
-    // One pass of one item: color_at up to the end of the lane's first shade_hit, then -- the wave
-    // together -- its children into the next generation's queue, or its colour to whoever waits for it.
-    // Returns false when the lane found no room and has to go again with `pending.open` cleared.
-    WfPending pending;
-    pending.open = true;
-    auto pass = [&](bool active, const Ray& ray, int remaining, uint32_t parent) -> bool {
-        bool deferred = false;
-        Shade sd;
-        V3 c = v3(0.0, 0.0, 0.0);
-        const Ctx<STATS, FLAT> before = cx;
-        if (active && PRIMARY) count(cx, ST_RAY_PRIMARY);
-        if (active) c = color_at(S, W, frames, ray, remaining, cx, pending, deferred, sd);
-        Children ch;
-        ch.do_reflect = ch.do_refract = ch.use_schlick = false;
-        double reflective = 0.0, transparency = 0.0;
-        bool want = false;
-        if (active && deferred) {
-            const RtMaterial m = S.mats[sd.mat];
-            reflective = m.reflective, transparency = m.transparency;
-            shade_children(m, sd, Ray{sd.over, sd.reflect_v}, remaining, ch, cx);
-            want = ch.do_reflect || ch.do_refract;
-            if (!want) c = combine(sd.surface, v3(0.0, 0.0, 0.0), v3(0.0, 0.0, 0.0), ch.use_schlick, ch.reflectance);
-        }
-        const bool placed = wf_commit(ws, out_shard, level, want, parent, sd.surface, reflective, transparency, ch, sd.over,
-                                      sd.reflect_v, remaining - 1);
-        if (want && !placed) {  // no room: forget this pass, the next one keeps the subtree
-            const unsigned flags = cx.status;
-            cx = before;
-            cx.status |= flags;
-            pending.open = false;
-            return false;
-        }
-        if (placed) {
-            if (ch.do_reflect) count(cx, ST_RAY_REFLECT);
-            if (ch.do_refract) count(cx, ST_RAY_REFRACT);
-        } else if (active) {
-            wf_deliver(ws.nodes, out, parent, c);
-        }
-        pending.open = true;
-        return true;
-    };
-    if constexpr (PRIMARY) {
-        const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-        const unsigned x = blockIdx.x * 16u + (wave & 1u) * 8u + (lane & 7u);
-        const unsigned k = blockIdx.y * 16u + (wave >> 1) * 8u + (lane >> 3);
-        bool active = x < cam.hsize && k < rows.n_local_rows;
-        unsigned y = 0;
-        if (active) {
-            y = ((k / rows.band_rows) * rows.n_parts + rows.part) * rows.band_rows + k % rows.band_rows;
-            active = y < cam.vsize;
-        }
-        while (__builtin_amdgcn_ballot_w64(active) != 0ull) {  // at most twice
-            // (the camera record is read from the workspace so that it need not stay in registers)
-            const Ray ray = active ? ray_for_pixel(*ws.cam, x, y) : Ray{v3(0.0, 0.0, 0.0), v3(0.0, 0.0, 1.0)};
-            if (pass(active, ray, depth, RT_WF_PIXEL | (k * ws.cam->hsize + x))) active = false;
-        }
-    } else {
-        const unsigned in_shard = blockIdx.x % RT_WF_SHARDS;
-        // the shard's slice, octant by octant, as one sequence
-        const unsigned sub_cap = ws.q_cap / RT_WF_BINS;
-        unsigned upto[RT_WF_BINS];
-        unsigned n_items = 0;
-#pragma unroll
-        for (unsigned o = 0; o < RT_WF_BINS; ++o) {
-            const unsigned n = ws.shards[in_shard].items[level & 1u][o];
-            n_items += n < sub_cap ? n : sub_cap;
-            upto[o] = n_items;
-        }
-        const unsigned stride = (gridDim.x / RT_WF_SHARDS) * blockDim.x;
-        const WfItem* q_in = ws.queue[level & 1u] + (size_t)in_shard * ws.q_cap;
-        unsigned i = (blockIdx.x / RT_WF_SHARDS) * blockDim.x + threadIdx.x;
-        while (i < n_items) {
-            unsigned o = 0, first = 0;
-#pragma unroll
-            for (unsigned b = 0; b + 1u < RT_WF_BINS; ++b)
-                if (i >= upto[b]) o = b + 1u, first = upto[b];
-            const WfItem* it = q_in + (size_t)o * sub_cap + (i - first);
-            out_shard = ((in_shard + RT_WF_SHARDS * ((unsigned)__builtin_amdgcn_readfirstlane((int)i) >> RT_WF_CHUNK_SHIFT)) * 2654435761u) >> 24;
-            if (pass(it->remaining != RT_WF_EMPTY, it->ray, (int)it->remaining, it->parent)) i += stride;
-        }
-    }
-    flush_stats(cx, stats, status);
+__global__ void wf_set_camera_kernel(RtCameraDesc* dst, const RtCameraDesc cam) {
+    if (threadIdx.x == 0) *dst = cam;
 }
 
 // generation g is traced: its nodes end here, generation g + 1's begin
@@ -298,96 +47,6 @@ __global__ __launch_bounds__(256) void wf_combine_kernel(WfSpace ws, unsigned le
     }
 }
 
-template <int FLAT>
-__global__ __launch_bounds__(256, FLAT == RT_CLASS_FLAT ? RT_WAVES_PER_SIMD_FLAT : RT_WAVES_PER_SIMD) void color_at_kernel(const SceneDev S, const double* __restrict__ rays,
-                                                       unsigned n, int depth, double* __restrict__ out,
-                                                       unsigned* __restrict__ status) {
-    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-    Ctx<false, FLAT> cx;
-    cx.status = 0;
-    if (i < n) {
-        Scratch W;
-        Frame frames[RT_MAX_DEPTH + 1];
-        const double* r = rays + (size_t)i * 6u;
-        const Ray ray{v3(r[0], r[1], r[2]), v3(r[3], r[4], r[5])};
-        const V3 c = color_at(S, W, frames, ray, depth, cx);
-        out[(size_t)i * 3u] = c.x;
-        out[(size_t)i * 3u + 1u] = c.y;
-        out[(size_t)i * 3u + 2u] = c.z;
-    }
-    flush_stats(cx, nullptr, status);
-}
-
-template <int FLAT>
-__global__ __launch_bounds__(256) void probe_kernel(const SceneDev S, const double* __restrict__ rays, unsigned n,
-                                                    double* __restrict__ out, unsigned* __restrict__ status) {
-    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-    Ctx<false, FLAT> cx;
-    cx.status = 0;
-    if (i < n) {
-        Scratch W;
-        const double* r = rays + (size_t)i * 6u;
-        double* o = out + (size_t)i * 16u;
-        for (int k = 0; k < 16; ++k) o[k] = 0.0;
-        const Ray ray{v3(r[0], r[1], r[2]), v3(r[3], r[4], r[5])};
-        Best hit;
-        if (find_hit(S, W, ray, hit, cx)) {
-            Comps c;
-            prepare_computations(S, W, ray, hit, true, c, cx);
-            o[0] = 1.0, o[1] = hit.t, o[2] = (double)hit.idx, o[3] = c.n1, o[4] = c.n2, o[5] = c.inside ? 1.0 : 0.0;
-            o[6] = c.over_point.x, o[7] = c.over_point.y, o[8] = c.over_point.z;
-            o[9] = c.normal_v.x, o[10] = c.normal_v.y, o[11] = c.normal_v.z;
-            o[12] = c.reflect_v.x, o[13] = c.reflect_v.y, o[14] = c.reflect_v.z;
-            if (S.n_lights > 0u) {
-                const RtLight l = S.lights[0];
-                o[15] = is_shadowed(S, W, c.over_point, v3(l.position[0], l.position[1], l.position[2]), cx) ? 1.0 : 0.0;
-            }
-        }
-    }
-    flush_stats(cx, nullptr, status);
-}
-
-// exercises/shading.rs:44-57 per ray: closest hit of the scene, the hit shape's normal there and its
-// lighting at the point itself (no shadow test, normal not turned towards the eye).
-template <int FLAT>
-__global__ __launch_bounds__(256) void shade_rays_kernel(const SceneDev S, const RtLight light,
-                                                         const double* __restrict__ rays, unsigned n,
-                                                         double* __restrict__ out, uint8_t* __restrict__ out_hit,
-                                                         unsigned* __restrict__ status) {
-    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-    Ctx<false, FLAT> cx;
-    cx.status = 0;
-    if (i < n) {
-        Scratch W;
-        const double* r = rays + (size_t)i * 6u;
-        const Ray ray{v3(r[0], r[1], r[2]), v3(r[3], r[4], r[5])};
-        V3 c = v3(0.0, 0.0, 0.0);
-        Best hit;
-        const bool found = find_hit(S, W, ray, hit, cx);
-        if (found) {
-            const RtShape* __restrict__ sh = S.shapes + hit.idx;
-            const unsigned kind = RT_KIND(sh->kind_flags);
-            int chain[RT_STACK];
-            const int nc = FLAT == RT_CLASS_FLAT ? 0 : ancestor_chain(S, sh->parent, chain);
-            const V3 point = ray.o + ray.d * hit.t;
-            const V3 local_point = world_to_object(S, sh, chain, nc, point);
-            const V3 normal = normal_to_world(S, sh, chain, nc, local_normal(S, sh, kind, local_point, chain, nc, ray));
-            const RtMaterial m = S.mats[sh->material];
-            V3 color = v3(m.color[0], m.color[1], m.color[2]);
-            if (m.pattern >= 0) {
-                unsigned nodes = 0;
-                color = pattern_eval(S.pats, m.pattern, local_point, nodes);
-            }
-            c = lighting(m, color, light, point, -ray.d, normal, false, cx);
-        }
-        out[(size_t)i * 3u] = c.x;
-        out[(size_t)i * 3u + 1u] = c.y;
-        out[(size_t)i * 3u + 2u] = c.z;
-        if (out_hit) out_hit[i] = found ? 1 : 0;
-    }
-    flush_stats(cx, nullptr, status);
-}
-
 // Canvas::scale_to_ppm_data (canvas.rs:85-90)
 __global__ __launch_bounds__(256) void quantize_kernel(const double* __restrict__ rgb, unsigned long long n,
                                                        uint8_t* __restrict__ out) {
@@ -409,15 +68,13 @@ std::mutex g_mutex;
 bool g_initialised = false;
 int g_device = -1;
 
-int hip_fail(hipError_t e, const char* what) {
+}  // namespace
+int rth::hip_fail(hipError_t e, const char* what) {
     g_hip_error = std::string(what) + ": " + hipGetErrorString(e);
     return RT_ERR_HIP;
 }
-#define HIP_TRY(expr)                                      \
-    do {                                                   \
-        const hipError_t e_ = (expr);                      \
-        if (e_ != hipSuccess) return hip_fail(e_, #expr); \
-    } while (0)
+namespace {
+using rth::hip_fail;
 
 int ensure_device() {
     if (g_initialised) return RT_OK;
@@ -433,6 +90,32 @@ int ensure_device() {
     g_initialised = true;
     return RT_OK;
 }
+
+// A scene lives on the device that was current when it was created; every entry point that takes a scene runs
+// on that device whatever the calling thread's current device is (hipSetDevice is per host thread), and puts
+// the thread's device back when it returns.
+struct DeviceGuard {
+    int saved = -1;
+    bool switched = false;
+    int rc = RT_OK;
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&saved) != hipSuccess) {
+            rc = RT_ERR_NO_DEVICE;
+            return;
+        }
+        if (saved != device) {
+            const hipError_t e = hipSetDevice(device);
+            if (e != hipSuccess) rc = hip_fail(e, "hipSetDevice(scene's device)");
+            else switched = true;
+        }
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(saved);
+    }
+};
+#define RT_ON_DEVICE_OF(scene)                \
+    DeviceGuard device_guard((scene)->device); \
+    if (device_guard.rc != RT_OK) return device_guard.rc
 
 template <class T>
 int upload(const T* src, size_t n, T** dst) {
@@ -547,33 +230,51 @@ int validate(const RtSceneDesc& d, uint32_t* flags_out) {
         if (nd.shape < 0 && k + 1 >= d.n_bvh_nodes) return RT_ERR_INVALID_SCENE;  // inner node needs a successor
     }
     if (d.world_bvh_root < -1 || d.world_bvh_root >= (int32_t)d.n_bvh_nodes) return RT_ERR_INVALID_SCENE;
-    if (d.world_bvh_root >= 0) {
-        // which nodes the world-level walk can reach, and whether one of their leaves names a shape that sits
-        // inside a group: the kernels then reach it through its ancestors (RT_CLASS_NESTED_LEAVES).  Such a
-        // leaf must be a primitive or a CSG node outside any CSG node (the direction index's contract).
-        std::vector<char> seen(d.n_bvh_nodes, 0);
-        std::vector<uint32_t> todo{(uint32_t)d.world_bvh_root};
-        bool has_group_leaf = false;  // a hierarchy with nested leaves names leaves only: its kernels never enter a group
+    // Which nodes each walk can reach.  A tree belongs to ONE level -- the world, or one group -- and names only
+    // shapes of that level: the traversal enters a level per leaf it descends into (`++level` on a stack of
+    // RT_STACK entries), so a group's tree naming the group itself, an ancestor or a shape of another depth
+    // would never terminate or run off that stack.  Trees of different levels share no node.
+    std::vector<int32_t> owner(d.n_bvh_nodes, -1);  // -1 unreached, -2 the world's tree, else the owning group's shape index
+    auto walk = [&](int32_t root, int32_t who, auto&& leaf_ok) -> bool {
+        std::vector<uint32_t> todo{(uint32_t)root};
         while (!todo.empty()) {
             const uint32_t k = todo.back();
             todo.pop_back();
-            if (seen[k]) continue;
-            seen[k] = 1;
+            if (owner[k] == who) continue;
+            if (owner[k] != -1) return false;
+            owner[k] = who;
             const RtBvhNode& nd = d.bvh_nodes[k];
             if (nd.miss >= 0) todo.push_back((uint32_t)nd.miss);
-            if (nd.shape < 0) {
+            if (nd.shape < 0)
                 todo.push_back(k + 1);
-                continue;
-            }
-            const RtShape& leaf = d.shapes[nd.shape];
-            if (RT_KIND(leaf.kind_flags) == RT_GROUP) has_group_leaf = true;
-            if (leaf.parent < 0) continue;
-            if (RT_KIND(leaf.kind_flags) == RT_GROUP) return RT_ERR_INVALID_SCENE;
-            for (int32_t a = leaf.parent; a >= 0; a = d.shapes[a].parent)
-                if (RT_KIND(d.shapes[a].kind_flags) == RT_CSG) return RT_ERR_INVALID_SCENE;
-            flags |= RT_SCENE_NESTED_LEAVES;
+            else if (!leaf_ok(d.shapes[nd.shape]))
+                return false;
         }
-        if ((flags & RT_SCENE_NESTED_LEAVES) && has_group_leaf) return RT_ERR_INVALID_SCENE;
+        return true;
+    };
+    if (d.world_bvh_root >= 0) {
+        // A world-level leaf is a top-level shape, or -- the global form of hierarchy -- a primitive or CSG node
+        // that sits inside groups and outside any CSG node (the direction index's contract): the kernels then
+        // reach it through its ancestors (RT_CLASS_NESTED_LEAVES) and never enter a group, so such a tree names
+        // no group at all.
+        bool has_group_leaf = false, ok = true;
+        ok = walk(d.world_bvh_root, -2, [&](const RtShape& leaf) {
+            if (RT_KIND(leaf.kind_flags) == RT_GROUP) has_group_leaf = true;
+            if (leaf.parent < 0) return true;
+            if (RT_KIND(leaf.kind_flags) == RT_GROUP) return false;
+            for (int32_t a = leaf.parent; a >= 0; a = d.shapes[a].parent)
+                if (RT_KIND(d.shapes[a].kind_flags) == RT_CSG) return false;
+            flags |= RT_SCENE_NESTED_LEAVES;
+            return true;
+        });
+        if (!ok || ((flags & RT_SCENE_NESTED_LEAVES) && has_group_leaf)) return RT_ERR_INVALID_SCENE;
+    }
+    for (uint32_t i = 0; i < d.n_shapes; ++i) {
+        const RtShape& s = d.shapes[i];
+        if (RT_KIND(s.kind_flags) != RT_GROUP || d.groups[s.param].bvh_root < 0) continue;
+        if (flags & RT_SCENE_NESTED_LEAVES) return RT_ERR_INVALID_SCENE;  // the global form leaves no tree to the groups
+        if (!walk(d.groups[s.param].bvh_root, (int32_t)i, [&](const RtShape& leaf) { return leaf.parent == (int32_t)i; }))
+            return RT_ERR_INVALID_SCENE;
     }
     if (d.world_bvh_root < 0) {
         bool flat = true;
@@ -631,11 +332,11 @@ int copy_to_host(void* dst, const void* d_src, size_t bytes) {
     }
     constexpr size_t kChunk = 16u << 20;
     const size_t n_chunks = (bytes + kChunk - 1) / kChunk;
+    HIP_TRY(hipDeviceSynchronize());  // the frame was written on the default stream
     hipStream_t stream = nullptr;
     HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     std::vector<hipEvent_t> done(n_chunks, nullptr);
     int rc = RT_OK;
-    HIP_TRY(hipDeviceSynchronize());  // the frame was written on the default stream
     for (size_t k = 0; k < n_chunks && rc == RT_OK; ++k) {
         const size_t off = k * kChunk, len = bytes - off < kChunk ? bytes - off : kChunk;
         if (hipMemcpyAsync(static_cast<char*>(g_staging) + off, static_cast<const char*>(d_src) + off, len,
@@ -667,22 +368,6 @@ int copy_to_host(void* dst, const void* d_src, size_t bytes) {
 
 }  // namespace
 
-struct RtScene {
-    SceneDev dev;      // host copy of the table pointers
-    SceneDev* d_dev;   // the same record in device memory: what the kernels read
-    unsigned* d_status;
-    int device;
-    std::vector<void*> allocations;
-    // wave-front workspace (queues, node pool, counters), sized by the largest frame rendered so far;
-    // launches on one scene are not re-entrant, so it is simply reused
-    mutable WfSpace wf;
-    mutable size_t wf_pixels;
-    mutable double* d_frame;           // rt_hip_scene_render*: device framebuffers, grown to the largest frame asked for
-    mutable uint8_t* d_frame8;
-    mutable size_t frame_values;
-    int wf_mode;                       // rt_hip_scene_set_wavefront: -1 by policy, 0 never, 1 whenever the scene can recurse
-    size_t wf_q_items, wf_node_items;  // capacities asked for (0: the defaults, per pixel of the frame)
-};
 
 namespace {
 
@@ -717,7 +402,13 @@ int read_status(const RtScene* scene, hipStream_t stream) {
 #define RT_WF_NODES_PER_PIXEL 3u  // past that a hit keeps its subtree to itself (slower, same result)
 #endif
 
-// RT_HIP_WAVEFRONT=0/1 in the environment overrides the policy for scenes left at "by policy" (experiments)
+}  // namespace
+void rth::launch_combine(const WfSpace& ws, unsigned level, double* d_out, hipStream_t stream) {
+    hipLaunchKernelGGL(wf_combine_kernel, dim3(RT_WF_GRID), dim3(256), 0, stream, ws, level, d_out);
+}
+namespace {
+
+// RT_HIP_WAVEFRONT=0/1/2 in the environment overrides the policy for scenes left at "by policy" (experiments)
 int wavefront_env() {
     static const int v = [] {
         const char* e = std::getenv("RT_HIP_WAVEFRONT");
@@ -790,13 +481,25 @@ int launch_render(const RtScene* scene, const RtCameraDesc* cam, uint32_t depth,
     const size_t pixels = (size_t)cam->hsize * rows.n_local_rows;
     const bool can_wavefront = (scene->dev.flags & RT_SCENE_RECURSIVE) != 0 && depth > 0 && pixels < 0x20000000ull;
     const int mode = scene->wf_mode >= 0 ? scene->wf_mode : wavefront_env();
-    const bool wavefront = can_wavefront && (mode == 1 || (mode < 0 && !flat && scene->dev.n_shapes >= RT_WF_MIN_SHAPES));
+    const bool large = !flat && scene->dev.n_shapes >= RT_WF_MIN_SHAPES;
+    // The kernel pipeline (rt_wf2.h) for the large scenes it covers: traversal in kernels of its own with persistent
+    // waves over a 4-wide hierarchy, shading in between.  If its workspace cannot be had the one-launch kernel below
+    // renders the same frame.
+    if (scene->wf2 && pixels < 0x20000000ull && (mode == 2 || (mode < 0 && large && can_wavefront))) {
+        const int rc = rth::wf2_render(scene, cam, depth, rows, d_out, stream, d_stats);
+        if (rc != RT_ERR_HIP) return rc;
+        (void)hipGetLastError();
+    }
+    bool wavefront = can_wavefront && (mode >= 1 || (mode < 0 && large));
+    if (wavefront && ensure_wavefront_space(scene, pixels) != RT_OK) {  // no room for queues and nodes: same frame, one launch
+        (void)hipGetLastError();
+        wavefront = false;
+    }
     if (wavefront) {
-        const int rc = ensure_wavefront_space(scene, pixels);
-        if (rc != RT_OK) return rc;
         const WfSpace ws = scene->wf;
         HIP_TRY(hipMemsetAsync(ws.shards, 0, RT_WF_SHARDS * sizeof(WfShard), stream));
-        HIP_TRY(hipMemcpyAsync(const_cast<RtCameraDesc*>(ws.cam), cam, sizeof(RtCameraDesc), hipMemcpyHostToDevice, stream));
+        // (the camera record travels as a kernel argument: the caller's *cam may be gone when the stream gets here)
+        hipLaunchKernelGGL(wf_set_camera_kernel, dim3(1), dim3(64), 0, stream, const_cast<RtCameraDesc*>(ws.cam), *cam);
         auto level = [&](auto primary, auto later, unsigned k) {
             if (k == 0)
                 hipLaunchKernelGGL(primary, grid, block, lds, stream, scene->dev, *cam, (int)depth, rows, d_out, d_stats,
@@ -821,7 +524,7 @@ int launch_render(const RtScene* scene, const RtCameraDesc* cam, uint32_t depth,
             hipLaunchKernelGGL(wf_mark_kernel, dim3(1), dim3(RT_WF_SHARDS), 0, stream, ws, k);
         }
         for (unsigned k = depth; k-- > 0;)  // generation `depth` has no budget left and so no nodes
-            hipLaunchKernelGGL(wf_combine_kernel, dim3(RT_WF_GRID), block, 0, stream, ws, k, d_out);
+            rth::launch_combine(ws, k, d_out, stream);
         HIP_TRY(hipGetLastError());
         return RT_OK;
     }
@@ -936,12 +639,13 @@ int rt_hip_scene_create(const RtSceneDesc* desc, RtScene** out) {
     std::memset(&s->dev, 0, sizeof s->dev);
     s->d_status = nullptr;
     s->d_dev = nullptr;
-    s->device = g_device;
+    if (hipGetDevice(&s->device) != hipSuccess) s->device = g_device;  // the calling thread's current device
     std::memset(&s->wf, 0, sizeof s->wf);
     s->wf_pixels = 0;
     s->d_frame = nullptr, s->d_frame8 = nullptr, s->frame_values = 0;
     s->wf_mode = -1;
     s->wf_q_items = s->wf_node_items = 0;
+    s->wf2 = nullptr;
     for (uint32_t k = 0; k < desc->n_materials; ++k)  // world.rs:99,110: these are the only tests that let color_at recurse
         if (desc->materials[k].reflective != 0.0 || desc->materials[k].transparency != 0.0) flags |= RT_SCENE_RECURSIVE;
     int rc = RT_OK;
@@ -1040,6 +744,7 @@ int rt_hip_scene_create(const RtSceneDesc* desc, RtScene** out) {
             if (e2 != hipSuccess) rc = hip_fail(e2, "hipMemcpy(scene record)");
         }
     }
+    if (rc == RT_OK) rc = rth::wf2_create(*desc, flags, &s->wf2);
     if (rc != RT_OK) {
         rt_hip_scene_destroy(s);
         return rc;
@@ -1050,16 +755,18 @@ int rt_hip_scene_create(const RtSceneDesc* desc, RtScene** out) {
 
 void rt_hip_scene_destroy(RtScene* scene) {
     if (!scene) return;
+    DeviceGuard device_guard(scene->device);
     for (void* p : scene->allocations) (void)hipFree(p);
     if (scene->d_frame) (void)hipFree(scene->d_frame);
     if (scene->d_frame8) (void)hipFree(scene->d_frame8);
     for (void* p : {(void*)scene->wf.queue[0], (void*)scene->wf.queue[1], (void*)scene->wf.nodes, (void*)scene->wf.shards})
         if (p) (void)hipFree(p);
+    rth::wf2_destroy(scene->wf2);
     delete scene;
 }
 
 int rt_hip_scene_set_wavefront(RtScene* scene, int mode, uint64_t queue_items, uint64_t node_items) {
-    if (!scene || mode < -1 || mode > 1) return RT_ERR_INVALID_ARG;
+    if (!scene || mode < -1 || mode > 2) return RT_ERR_INVALID_ARG;
     if (queue_items >= 0x80000000ull || node_items >= 0x40000000ull) return RT_ERR_INVALID_ARG;
     scene->wf_mode = mode;
     if (scene->wf_q_items != queue_items || scene->wf_node_items != node_items) {
@@ -1069,8 +776,26 @@ int rt_hip_scene_set_wavefront(RtScene* scene, int mode, uint64_t queue_items, u
     return RT_OK;
 }
 
+const char* rt_hip_scene_kernels(const RtScene* scene, uint32_t depth) {
+    if (!scene) return "";
+    // (the choices of launch_render, in its order)
+    const bool flat = (scene->dev.flags & RT_SCENE_FLAT) != 0;
+    const bool recursive = (scene->dev.flags & RT_SCENE_RECURSIVE) != 0 && depth > 0;
+    const int mode = scene->wf_mode >= 0 ? scene->wf_mode : wavefront_env();
+    const bool large = !flat && scene->dev.n_shapes >= RT_WF_MIN_SHAPES;
+    if (scene->wf2 && (mode == 2 || (mode < 0 && large && recursive))) return rth::wf2_describe();
+    if (recursive && (mode >= 1 || (mode < 0 && large)))
+        return "one launch per generation of rays: wf_level_kernel (camera rays, then queue slices) + wf_mark_kernel + wf_combine_kernel";
+    if (flat) return scene->dev.stage_bytes ? "render_kernel, flat scene class, tables and hit lists staged in LDS" : "render_kernel, flat scene class";
+    if (scene->dev.flags & RT_SCENE_NESTED_LEAVES)
+        return scene->dev.stage_bytes ? "render_kernel, world-level hierarchy over nested leaves, tables staged in LDS"
+                                      : "render_kernel, world-level hierarchy over nested leaves";
+    return scene->dev.stage_bytes ? "render_kernel, general scene class (groups / CSG), tables staged in LDS" : "render_kernel, general scene class (groups / CSG)";
+}
+
 int rt_hip_scene_status(const RtScene* scene, void* hip_stream) {
     if (!scene) return RT_ERR_INVALID_ARG;
+    RT_ON_DEVICE_OF(scene);
     return read_status(scene, static_cast<hipStream_t>(hip_stream));
 }
 
@@ -1078,6 +803,7 @@ int rt_hip_render_rows(const RtScene* scene, const RtCameraDesc* cam, uint32_t d
                        uint32_t band_rows, uint32_t n_local_rows, double* d_out_rgb, void* hip_stream,
                        RtStats* d_stats) {
     if (!scene || !d_out_rgb || n_parts == 0 || part >= n_parts || band_rows == 0) return RT_ERR_INVALID_ARG;
+    RT_ON_DEVICE_OF(scene);
     const int rc = check_camera(cam, depth);
     if (rc != RT_OK) return rc;
     if (n_local_rows == 0) return RT_OK;
@@ -1091,6 +817,7 @@ int rt_hip_render_rows(const RtScene* scene, const RtCameraDesc* cam, uint32_t d
 static int scene_render_to_host(const RtScene* scene, const RtCameraDesc* cam, uint32_t depth, double* out_rgb,
                                 uint8_t* out_rgb8, RtStats* stats) {
     if (!scene || (!out_rgb && !out_rgb8)) return RT_ERR_INVALID_ARG;
+    RT_ON_DEVICE_OF(scene);
     const int crc0 = check_camera(cam, depth);
     if (crc0 != RT_OK) return crc0;
     const size_t n_values = (size_t)cam->hsize * cam->vsize * 3u;
@@ -1183,6 +910,7 @@ int rt_hip_render_rgb8(const RtSceneDesc* desc, const RtCameraDesc* cam, uint32_
 int rt_hip_color_at(const RtScene* scene, const double* rays, uint32_t n, uint32_t depth, double* out_rgb) {
     if (!scene || (n && (!rays || !out_rgb))) return RT_ERR_INVALID_ARG;
     if (depth > RT_MAX_DEPTH) return RT_ERR_DEPTH;
+    RT_ON_DEVICE_OF(scene);
     if (n == 0) return RT_OK;
     double *d_rays = nullptr, *d_out = nullptr;
     auto body = [&]() -> int {
@@ -1211,6 +939,7 @@ int rt_hip_color_at(const RtScene* scene, const double* rays, uint32_t n, uint32
 int rt_hip_shade_rays(const RtScene* scene, const RtLight* light, const double* rays, uint32_t n, double* out_rgb,
                       uint8_t* out_hit) {
     if (!scene || !light || (n && (!rays || !out_rgb))) return RT_ERR_INVALID_ARG;
+    RT_ON_DEVICE_OF(scene);
     if (n == 0) return RT_OK;
     double *d_rays = nullptr, *d_out = nullptr;
     uint8_t* d_hit = nullptr;
@@ -1243,6 +972,7 @@ int rt_hip_shade_rays(const RtScene* scene, const RtLight* light, const double* 
 
 int rt_hip_probe(const RtScene* scene, const double* rays, uint32_t n, double* out) {
     if (!scene || (n && (!rays || !out))) return RT_ERR_INVALID_ARG;
+    RT_ON_DEVICE_OF(scene);
     if (n == 0) return RT_OK;
     double *d_rays = nullptr, *d_out = nullptr;
     auto body = [&]() -> int {

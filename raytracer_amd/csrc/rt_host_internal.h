@@ -1,0 +1,51 @@
+// rt_host_internal.h -- what the host-side translation units of librt_hip.so share (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "rt_kernels.h"
+
+namespace rth {
+// records the text for rt_hip_last_hip_error (thread-local) and returns RT_ERR_HIP
+int hip_fail(hipError_t e, const char* what);
+}  // namespace rth
+#define HIP_TRY(expr)                                           \
+    do {                                                        \
+        const hipError_t e_ = (expr);                           \
+        if (e_ != hipSuccess) return rth::hip_fail(e_, #expr); \
+    } while (0)
+
+struct Wf2;  // rt_wf2.hip: the 4-wide hierarchy and workspace of the kernel pipeline for large scenes
+
+struct RtScene {
+    rtd::SceneDev dev;      // host copy of the table pointers
+    rtd::SceneDev* d_dev;   // the same record in device memory: what the kernels read
+    unsigned* d_status;
+    int device;
+    std::vector<void*> allocations;
+    // wave-front workspace (queues, node pool, counters), sized by the largest frame rendered so far;
+    // launches on one scene are not re-entrant, so it is simply reused
+    mutable rtd::WfSpace wf;
+    mutable size_t wf_pixels;
+    mutable double* d_frame;           // rt_hip_scene_render*: device framebuffers, grown to the largest frame asked for
+    mutable uint8_t* d_frame8;
+    mutable size_t frame_values;
+    int wf_mode;                       // rt_hip_scene_set_wavefront: -1 by policy, 0 one launch, 1 a launch per generation, 2 the kernel pipeline
+    size_t wf_q_items, wf_node_items;  // capacities asked for (0: the defaults, per pixel of the frame)
+    Wf2* wf2;                          // non-null when the scene qualifies for the kernel pipeline
+};
+
+namespace rth {
+// rt_wf2.hip.  wf2_create leaves *out null (and returns RT_OK) for scenes the pipeline does not cover.
+int wf2_create(const RtSceneDesc& desc, uint32_t scene_flags, Wf2** out);
+void wf2_destroy(Wf2* w);
+// One frame (or row-band shard) through the pipeline, asynchronously on `stream`.  RT_ERR_HIP when the workspace
+// cannot be had: the caller then falls back to the one-launch kernel (same frame).
+int wf2_render(const RtScene* scene, const RtCameraDesc* cam, uint32_t depth, const rtk::RowMap& rows, double* d_out,
+               hipStream_t stream, RtStats* d_stats);
+const char* wf2_describe();
+// rt_hip.hip: shade_hit's last line for the nodes of one generation (used by both wave-front forms)
+void launch_combine(const rtd::WfSpace& ws, unsigned level, double* d_out, hipStream_t stream);
+}  // namespace rth

@@ -1,0 +1,733 @@
+// rt_wf2.h -- the render path of LARGE scenes as a pipeline of kernels per generation of rays
+// ("wave-front" organisation, second form).  Same functions, same arithmetic and therefore the same
+// frame, bit for bit, as render_kernel / wf_level_kernel; what changes is who does what when:
+//
+//   wf2_cands_kernel     direction-index candidates of every ray of the generation (primitive.rs:486-490's
+//                        branch, see RtDirCand) -> the ray's starting hit record / shadow flag
+//   wf2_trace_kernel     World::intersections + hit (world.rs:45-53, intersection.rs:154-158), closest hit or
+//                        shadow any-hit (world.rs:85-96): NOTHING but traversal.  Persistent waves: a lane
+//                        whose ray is done takes the next ray of the queue, so the lanes of a wave stay busy
+//                        however unequal their walks are (in wf_level_kernel two lanes in three idled).
+//                        The walk is over a 4-wide hierarchy with conservative f32 boxes (one 128-byte node
+//                        read yields four child boxes: a quarter of the dependent reads of the 2-wide
+//                        skip-link walk, box arithmetic in packed f32 instead of f64); every leaf the walk
+//                        reaches is tested with the reference's own f64 arithmetic, so no decision changes.
+//   wf2_prepare_kernel   prepare_computations + the pattern colour (intersection.rs:45-99, pattern.rs:76-91) of
+//                        every hit; hits are compacted into shading contexts, one shadow feeler per light each
+//   wf2_containers_kernel  n1 / n2 (intersection.rs:50-75) for the transparent hits only
+//   wf2_finish_kernel    lighting per light (primitive.rs:111-151), reflected / refracted children
+//                        (world.rs:98-127, schlick intersection.rs:182-200) into the next generation's queue
+//   wf2_overflow_kernel  hits whose children found no room keep their subtree (color_at's frame stack)
+//   wf2_compact_kernel   the next generation's queue made dense
+// and wf_combine_kernel folds children into parents from the deepest generation upwards (world.rs:76-82).
+#pragma once
+#include "rt_kernels.h"
+
+namespace rtk {
+
+// ---- 4-wide hierarchy (acceleration only; built by the library from the skip-link nodes of the scene) -----------
+struct __attribute__((aligned(128))) Bvh4Node {
+    float lo[3][4];    // lo[axis][child]: the child's padded box, rounded outward
+    float hi[3][4];
+    int32_t child[4];  // inner node index, RT_BVH4_LEAF | shape index, or RT_BVH4_DONE for an empty slot (box inverted)
+    uint32_t pad[4];
+};
+static_assert(sizeof(Bvh4Node) == 128, "one node = one 128-byte line");
+#define RT_BVH4_LEAF 0x80000000u
+#define RT_BVH4_DONE 0x7fffffffu
+#define RT_WF2_LDS_STACK 24   // stack entries per lane kept in LDS; deeper ones in private memory
+#define RT_WF2_MAX_STACK 96   // scenes whose 4-wide tree could need more keep the older kernels
+
+struct Wf2Accel {
+    const Bvh4Node* nodes;
+    uint32_t root;       // inner node index, or a leaf / DONE code when the tree is that small
+    float extent[3];     // largest |coordinate| of any finite box, per axis: scales the f32 slack of the box test
+    uint32_t has_cands;  // the scene has a direction index
+};
+
+struct Wf2Hit {  // closest hit of one colour ray
+    double t;
+    int32_t idx;
+    uint32_t pad;
+};
+
+// Shading contexts of one generation's hits, one slot per hit, structure-of-arrays so that the lanes of a
+// wave read and write consecutive words.
+enum { CX_OVER = 0, CX_UNDER = 3, CX_EYE = 6, CX_NORMAL = 9, CX_REFLECT = 12, CX_COLOR = 15, CX_SURFACE = 18,
+       CX_T = 21, CX_N1 = 22, CX_N2 = 23, CX_DOUBLES = 24 };
+enum { CU_MAT = 0, CU_PARENT = 1, CU_REMAINING = 2, CU_ITEM = 3, CU_UINTS = 4 };
+
+struct Wf2Counters {
+    unsigned n_rays[RT_WF_LEVELS + 1];  // colour rays of generation g (dense queue length)
+    unsigned n_hits;                    // shading contexts of the generation at hand
+    unsigned n_creq;                    // ... of which transparent: containers requests
+    unsigned n_overflow;
+    unsigned chunk[2 * (RT_WF_LEVELS + 1)];  // next chunk of each trace launch (generation x {colour, shadow})
+    unsigned offsets[RT_WF_SHARDS * RT_WF_BINS + 1];  // compaction: start of each (shard, octant) sub-slice in the dense queue
+};
+
+struct Wf2Space {
+    WfSpace ws;        // node pool, shard counters and the sliced queue wf_commit fills (both queue pointers name it)
+    WfItem* qd;        // the generation's colour rays, dense
+    Wf2Hit* hits;      // one per colour ray
+    double* ctx_d;     // [CX_DOUBLES][ctx_cap]
+    uint32_t* ctx_u;   // [CU_UINTS][ctx_cap]
+    uint8_t* occ;      // [n_lights][ctx_cap]: light l is hidden from hit `slot`
+    uint32_t* creq;    // [ctx_cap]
+    uint32_t* overflow;  // [ctx_cap]
+    Wf2Counters* cnt;
+    unsigned qd_cap, ctx_cap;
+};
+
+#ifndef RT_WF2_CHUNK
+#define RT_WF2_CHUNK 256u  // rays a wave takes from the queue at a time
+#endif
+#ifndef RT_WF2_REFILL
+#define RT_WF2_REFILL 16   // idle lanes that make a wave go back to the queue
+#endif
+enum { WF2_PRIMARY = 0, WF2_QUEUE = 1, WF2_SHADOW = 2 };
+
+// Item i of generation 0 = one pixel, tiles of 8x8 in row-major tile order (neighbouring rays to one wave).
+struct PixelMap {
+    unsigned tiles_x, n_items;
+};
+RT_DEV PixelMap pixel_map(const RtCameraDesc& cam, const RowMap& rows) {
+    PixelMap m;
+    m.tiles_x = (cam.hsize + 7u) / 8u;
+    m.n_items = m.tiles_x * ((rows.batch_rows + 7u) / 8u) * 64u;
+    return m;
+}
+// -> false for the slots of a tile that fall outside the frame; k = local row, y = image row
+RT_DEV bool pixel_of_item(const RtCameraDesc& cam, const RowMap& rows, const PixelMap& m, unsigned i, unsigned& x, unsigned& k,
+                          unsigned& y) {
+    const unsigned tile = i >> 6, within = i & 63u;
+    x = (tile % m.tiles_x) * 8u + (within & 7u);
+    const unsigned kb = (tile / m.tiles_x) * 8u + (within >> 3);  // row of the batch
+    k = rows.row0 + kb;
+    y = 0;
+    if (!(x < cam.hsize && kb < rows.batch_rows && k < rows.n_local_rows)) return false;
+    y = ((k / rows.band_rows) * rows.n_parts + rows.part) * rows.band_rows + k % rows.band_rows;
+    return y < cam.vsize;
+}
+
+// The ray of item `i` of a launch: camera ray, queued colour ray, or the shadow feeler of (hit slot, light):
+// feelers are numbered light-major, so a wave's feelers go to ONE light from neighbouring hits.
+template <int MODE>
+RT_DEV bool wf2_item_ray(const SceneDev& S, const Wf2Space& sp, const RtCameraDesc& cam, const RowMap& rows, const PixelMap& pm,
+                         unsigned i, unsigned n_hits, Ray& ray, double& limit) {
+    limit = 0.0;
+    if constexpr (MODE == WF2_PRIMARY) {
+        unsigned x, k, y;
+        if (!pixel_of_item(cam, rows, pm, i, x, k, y)) return false;
+        ray = ray_for_pixel(cam, x, y);
+        return true;
+    } else if constexpr (MODE == WF2_QUEUE) {
+        const WfItem* it = sp.qd + i;
+        if (it->remaining == RT_WF_EMPTY) return false;
+        ray = it->ray;
+        return true;
+    } else {
+        const unsigned l = i / n_hits, slot = i - l * n_hits;
+        const double* cd = sp.ctx_d + slot;
+        const size_t st = sp.ctx_cap;
+        const V3 over = v3(cd[(CX_OVER + 0) * st], cd[(CX_OVER + 1) * st], cd[(CX_OVER + 2) * st]);
+        const RtLight light = S.lights[l];
+        const V3 v = v3(light.position[0], light.position[1], light.position[2]) - over;  // world.rs:86-89
+        limit = magnitude(v);
+        ray = Ray{over, normalize(v)};
+        return true;
+    }
+}
+
+// ---- the f32 side of a ray: conservative slab tests ------------------------------------------------------------
+// t_lo(axis, child) = lo * inv + cl, t_hi = hi * inv + ch with cl / ch = -o * inv shifted outward by the slack
+// K = |inv| * 2^-20 * (|o| + extent): every rounding of the f32 evaluation (o and inv rounded to f32, the product-sum,
+// and a relative 2^-23 of t, whose spatial size along the axis is bounded by |o| + extent) moves a plane by less.
+struct RayF32 {
+    float inv[3], cl[3], ch[3];
+};
+RT_DEV float f32_up(double x) { return __double2float_ru(x); }
+RT_DEV float f32_down(double x) { return __double2float_rd(x); }
+RT_DEV void ray_f32(const Ray& r, const float extent[3], RayF32& f) {
+    const double o[3] = {r.o.x, r.o.y, r.o.z}, d[3] = {r.d.x, r.d.y, r.d.z};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        double inv = 1.0 / d[a];
+        // a direction component of (almost) zero: any huge finite slope says the same about every box
+        if (!(fabs(inv) <= 1e18)) inv = (d[a] < 0.0 || (d[a] == 0.0 && __double_as_longlong(d[a]) < 0)) ? -1e18 : 1e18;
+        const float invf = (float)inv;
+        const double c = -o[a] * (double)invf;
+        const double k = fabs((double)invf) * (1.0 / 1048576.0) * (fabs(o[a]) + (double)extent[a]);
+        f.inv[a] = invf;
+        // the plane met first is lo when the slope is positive, hi when it is negative; first planes move down, second up
+        f.cl[a] = invf >= 0.f ? f32_down(c - k) : f32_up(c + k);
+        f.ch[a] = invf >= 0.f ? f32_up(c + k) : f32_down(c - k);
+    }
+}
+
+struct Walk {
+    uint32_t cur;  // node at hand: inner index, RT_BVH4_LEAF | shape, or RT_BVH4_DONE
+    int sp;        // stack entries (entry 0 is the DONE sentinel)
+};
+
+// One step of the walk at an inner node: the four child boxes against the ray segment [0, t_far]; the nearest
+// child met becomes the node at hand, the others go on the stack.
+template <bool STATS, int FLAT>
+RT_DEV void walk_step(const Wf2Accel& A, const RayF32& f, float t_far, Walk& w, uint32_t* lds_stack, uint32_t* deep,
+                      Ctx<STATS, FLAT>& cx) {
+    const Bvh4Node* __restrict__ nd = A.nodes + w.cur;
+    const float4* __restrict__ q = reinterpret_cast<const float4*>(nd);
+    const float4 lox = q[0], loy = q[1], loz = q[2], hix = q[3], hiy = q[4], hiz = q[5];
+    const int4 ch = *reinterpret_cast<const int4*>(nd->child);
+    count(cx, ST_BVH_BOX, 4u);
+    const float lo[3][4] = {{lox.x, lox.y, lox.z, lox.w}, {loy.x, loy.y, loy.z, loy.w}, {loz.x, loz.y, loz.z, loz.w}};
+    const float hi[3][4] = {{hix.x, hix.y, hix.z, hix.w}, {hiy.x, hiy.y, hiy.z, hiy.w}, {hiz.x, hiz.y, hiz.z, hiz.w}};
+    const uint32_t kid[4] = {(uint32_t)ch.x, (uint32_t)ch.y, (uint32_t)ch.z, (uint32_t)ch.w};
+    uint32_t next = RT_BVH4_DONE;
+    float t_next = __builtin_inff();
+    bool have = false;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float ax = __builtin_fmaf(lo[0][c], f.inv[0], f.cl[0]), bx = __builtin_fmaf(hi[0][c], f.inv[0], f.ch[0]);
+        const float ay = __builtin_fmaf(lo[1][c], f.inv[1], f.cl[1]), by = __builtin_fmaf(hi[1][c], f.inv[1], f.ch[1]);
+        const float az = __builtin_fmaf(lo[2][c], f.inv[2], f.cl[2]), bz = __builtin_fmaf(hi[2][c], f.inv[2], f.ch[2]);
+        const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+        const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+        // (negated comparisons: a NaN anywhere lets the box through, as the f64 walk does)
+        const bool met = kid[c] != RT_BVH4_DONE && !(tn > tf) && !(tf < 0.f) && !(tn > t_far);
+        if (met) {
+            uint32_t other = kid[c];
+            if (!have || tn < t_next) {
+                other = next;
+                next = kid[c];
+                t_next = tn;
+            }
+            if (have) {
+                if (w.sp < RT_WF2_LDS_STACK)
+                    lds_stack[w.sp * 64] = other;
+                else
+                    deep[w.sp - RT_WF2_LDS_STACK] = other;
+                ++w.sp;
+            }
+            have = true;
+        }
+    }
+    if (have) {
+        w.cur = next;
+    } else {
+        --w.sp;
+        w.cur = w.sp < RT_WF2_LDS_STACK ? lds_stack[w.sp * 64] : deep[w.sp - RT_WF2_LDS_STACK];
+    }
+}
+RT_DEV void walk_pop(Walk& w, const uint32_t* lds_stack, const uint32_t* deep) {
+    --w.sp;
+    w.cur = w.sp < RT_WF2_LDS_STACK ? lds_stack[w.sp * 64] : deep[w.sp - RT_WF2_LDS_STACK];
+}
+
+// A leaf of the world-level hierarchy (a primitive, possibly nested in groups; scenes with CSG nodes keep the older
+// kernels): the ray goes through the ancestors' transforms, outermost first, and the primitive is intersected with
+// the reference's arithmetic (shape.rs:28-32, primitive.rs:210-233).  The ancestors' gates (compound.rs:93-95)
+// decide whether the reference reaches the primitive at all; they are evaluated only when the primitive has a hit
+// to offer that could change the answer -- a hit behind a closed gate and no hit at all leave the same result.
+template <bool SHADOW, bool STATS, int FLAT>
+RT_DEV bool wf2_leaf(const SceneDev& S, int s, const Ray& world_ray, double limit, Best& best, Ctx<STATS, FLAT>& cx) {
+    const RtShape* __restrict__ sh = S.shapes + s;
+    const unsigned kf = sh->kind_flags;
+    if (SHADOW && !(kf & RT_FLAG_HAS_SHADOW)) return false;
+    const int parent = sh->parent;
+    Ray at = world_ray;
+    int chain[RT_STACK];
+    int n = 0;
+    if (parent >= 0) {
+        n = ancestor_chain(S, parent, chain);
+        for (int q = n - 1; q >= 0; --q) {
+            at = transform_ray(S.shapes[chain[q]].inv, at);
+            count(cx, ST_RAY_XFORM);
+        }
+    }
+    PrimHits h;
+    prim_intersect(S, sh, kf, at, h, cx);
+    bool useful = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if ((h.keep >> k) & 1u) {
+            const double t = h.t[k];
+            if (SHADOW)
+                useful = useful || (t >= 0.0 && t < limit);
+            else
+                useful = useful || (t >= 0.0 && (t < best.t || (t == best.t && s > best.idx)));
+        }
+    }
+    if (!useful) return false;
+    {  // the way down again, this time past the gates (the transforms were counted above)
+        Ray r = world_ray;
+        for (int q = n - 1; q >= 0; --q) {
+            const RtShape* __restrict__ g = S.shapes + chain[q];
+            r = transform_ray(g->inv, r);
+            if (RT_KIND(g->kind_flags) == RT_GROUP) {
+                const RtGroup* __restrict__ gg = S.groups + g->param;
+                count(cx, ST_GATES);
+                if (!(gg->n_children != 0u && box_intersects(gg->bmin, gg->bmax, r))) return false;
+            }
+        }
+    }
+    if (SHADOW) return true;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if ((h.keep >> k) & 1u) offer(best, h.t[k], s);
+    return false;
+}
+
+// Direction-index candidates of one ray, evaluated like the older kernels evaluate them (cand_next + process_leaf).
+template <bool SHADOW, bool STATS, int FLAT>
+RT_DEV bool wf2_candidates(const SceneDev& S, const Ray& ray, double limit, Best& best, Ctx<STATS, FLAT>& cx) {
+    CandIter it;
+    cand_begin(S, ray, it);
+    const V3 d = ray.d;
+    bool found = false;
+    while (it.k < it.e && !found) {
+        const RtDirCand* __restrict__ c = S.dir_cands + (it.scan_all ? it.k : S.dir_entries[it.k]);
+        ++it.k;
+        const double a = c->q[0] * d.x * d.x + c->q[1] * d.y * d.y + c->q[2] * d.z * d.z +
+                         2.0 * (c->q[3] * d.x * d.y + c->q[4] * d.x * d.z + c->q[5] * d.y * d.z);
+        if (!(fabs(a) <= c->thr)) continue;
+        found = wf2_leaf<SHADOW>(S, (int)c->visit, ray, limit, best, cx) && SHADOW;
+    }
+    return found;
+}
+
+template <bool STATS, int MODE>
+__global__ __launch_bounds__(256) void wf2_cands_kernel(const SceneDev S, Wf2Space sp, RtCameraDesc cam, RowMap rows, unsigned gen,
+                                                        RtStats* __restrict__ stats, unsigned* __restrict__ status) {
+    constexpr int CLS = RT_CLASS_NESTED_LEAVES;
+    Ctx<STATS, CLS> cx;
+    cx.status = 0;
+    if constexpr (STATS) {
+#pragma unroll
+        for (int i = 0; i < ST_COUNT; ++i) cx.cnt[i] = 0;
+    }
+    const PixelMap pm = pixel_map(cam, rows);
+    const unsigned n_hits = MODE == WF2_SHADOW ? sp.cnt->n_hits : 0u;
+    const unsigned n = MODE == WF2_PRIMARY ? pm.n_items : (MODE == WF2_QUEUE ? sp.cnt->n_rays[gen] : n_hits * S.n_lights);
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        Ray ray;
+        double limit;
+        Best best{__builtin_inf(), -1};
+        bool found = false;
+        if (wf2_item_ray<MODE>(S, sp, cam, rows, pm, i, n_hits, ray, limit))
+            found = wf2_candidates<MODE == WF2_SHADOW>(S, ray, limit, best, cx);
+        if constexpr (MODE == WF2_SHADOW) {
+            sp.occ[i] = found ? 1 : 0;  // feelers are numbered light * n_hits + slot, and so are their flags
+        } else {
+            Wf2Hit h;
+            h.t = best.t, h.idx = best.idx, h.pad = 0;
+            sp.hits[i] = h;
+        }
+    }
+    flush_stats(cx, stats, status);
+}
+
+// The traversal kernel.  One-wave blocks; every lane holds at most one ray.
+#ifndef RT_WF2_TRACE_WAVES
+#define RT_WF2_TRACE_WAVES 4  // waves per SIMD the traversal kernel is compiled for (<= 128 VGPRs)
+#endif
+template <bool STATS, int MODE>
+__global__ __launch_bounds__(64, RT_WF2_TRACE_WAVES) void wf2_trace_kernel(const SceneDev S, const Wf2Accel A, Wf2Space sp, RtCameraDesc cam, RowMap rows,
+                                                       unsigned gen, RtStats* __restrict__ stats, unsigned* __restrict__ status) {
+    constexpr int CLS = RT_CLASS_NESTED_LEAVES;
+    constexpr bool SHADOW = MODE == WF2_SHADOW;
+    __shared__ uint32_t lds_stack_all[RT_WF2_LDS_STACK * 64];
+    uint32_t* lds_stack = lds_stack_all + threadIdx.x;
+    uint32_t deep[RT_WF2_MAX_STACK - RT_WF2_LDS_STACK];
+    Ctx<STATS, CLS> cx;
+    cx.status = 0;
+    if constexpr (STATS) {
+#pragma unroll
+        for (int i = 0; i < ST_COUNT; ++i) cx.cnt[i] = 0;
+    }
+    const PixelMap pm = pixel_map(cam, rows);
+    const unsigned n_hits = SHADOW ? sp.cnt->n_hits : 0u;
+    const unsigned n = MODE == WF2_PRIMARY ? pm.n_items : (MODE == WF2_QUEUE ? sp.cnt->n_rays[gen] : n_hits * S.n_lights);
+    unsigned* chunk_counter = &sp.cnt->chunk[2u * gen + (SHADOW ? 1u : 0u)];
+    const unsigned lane = threadIdx.x;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    unsigned chunk_next = 0, chunk_end = 0;  // wave-uniform
+    bool dry = false;                        // the queue has no chunk left
+    bool busy = false;
+    unsigned item = 0;
+    Ray ray{v3(0.0, 0.0, 0.0), v3(0.0, 0.0, 1.0)};
+    RayF32 f{};
+    Best best{__builtin_inf(), -1};
+    double limit = 0.0;
+    bool found = false;
+    float t_far = 0.f;
+    Walk w{RT_BVH4_DONE, 0};
+    for (;;) {
+        // ---- refill: idle lanes take the next rays of the wave's chunk
+        const unsigned long long idle = __builtin_amdgcn_ballot_w64(!busy);
+        const int n_idle = __builtin_popcountll(idle);
+        if (n_idle == 64 || (n_idle >= RT_WF2_REFILL && !dry)) {
+            if (chunk_next >= chunk_end && !dry) {
+                unsigned c = 0;
+                if (lane == 0) c = atomicAdd(chunk_counter, RT_WF2_CHUNK);
+                c = (unsigned)__builtin_amdgcn_readfirstlane((int)c);
+                if (c < n) {
+                    chunk_next = c;
+                    chunk_end = c + RT_WF2_CHUNK < n ? c + RT_WF2_CHUNK : n;
+                } else {
+                    dry = true;
+                }
+            }
+            const unsigned avail = chunk_end - chunk_next;
+            if (avail != 0u) {
+                const unsigned rank = (unsigned)__builtin_popcountll(idle & below);
+                if (!busy && rank < avail) {
+                    item = chunk_next + rank;
+                    busy = true;
+                    best.t = __builtin_inf(), best.idx = -1;
+                    found = false;
+                    const bool valid = wf2_item_ray<MODE>(S, sp, cam, rows, pm, item, n_hits, ray, limit);
+                    if (A.has_cands) {  // what the direction index already found for this ray
+                        if constexpr (SHADOW) {
+                            found = sp.occ[item] != 0;
+                        } else {
+                            const Wf2Hit h0 = sp.hits[item];
+                            best.t = h0.t, best.idx = h0.idx;
+                        }
+                    }
+                    ray_f32(ray, A.extent, f);
+                    t_far = SHADOW ? f32_up(limit) : f32_up(best.t);
+                    lds_stack[0] = RT_BVH4_DONE;
+                    w.sp = 1;
+                    w.cur = (valid && !found) ? A.root : RT_BVH4_DONE;
+                    // (reflected / refracted rays are counted where they are queued, as in wf_level_kernel)
+                    if (valid && MODE != WF2_QUEUE) count(cx, SHADOW ? ST_RAY_SHADOW : ST_RAY_PRIMARY);
+                }
+                chunk_next += (unsigned)n_idle < avail ? (unsigned)n_idle : avail;
+            } else if (n_idle == 64) {
+                break;  // nothing in flight, nothing left
+            }
+        }
+        // ---- box tests only, until every busy lane holds a leaf or is through
+        while (busy && w.cur < RT_BVH4_DONE) walk_step(A, f, t_far, w, lds_stack, deep, cx);
+        // ---- leaves
+        if (busy && (w.cur & RT_BVH4_LEAF)) {
+            const int s = (int)(w.cur & ~RT_BVH4_LEAF);
+            const bool hit_shadow = wf2_leaf<SHADOW>(S, s, ray, limit, best, cx);
+            if (SHADOW) {
+                if (hit_shadow) {
+                    found = true;
+                    w.cur = RT_BVH4_DONE;
+                } else {
+                    walk_pop(w, lds_stack, deep);
+                }
+            } else {
+                t_far = f32_up(best.t);
+                walk_pop(w, lds_stack, deep);
+            }
+        }
+        // ---- rays that are through
+        if (busy && w.cur == RT_BVH4_DONE) {
+            if constexpr (SHADOW) {
+                sp.occ[item] = found ? 1 : 0;
+            } else {
+                Wf2Hit h;
+                h.t = best.t, h.idx = best.idx, h.pad = 0;
+                sp.hits[item] = h;
+            }
+            busy = false;
+        }
+    }
+    flush_stats(cx, stats, status);
+}
+
+
+// ---- shading contexts -----------------------------------------------------------------------------------------
+RT_DEV V3 ctx_v3(const Wf2Space& sp, unsigned slot, int field) {
+    const double* p = sp.ctx_d + (size_t)field * sp.ctx_cap + slot;
+    return v3(p[0], p[sp.ctx_cap], p[2 * (size_t)sp.ctx_cap]);
+}
+RT_DEV void ctx_put(const Wf2Space& sp, unsigned slot, int field, V3 v) {
+    double* p = sp.ctx_d + (size_t)field * sp.ctx_cap + slot;
+    p[0] = v.x, p[sp.ctx_cap] = v.y, p[2 * (size_t)sp.ctx_cap] = v.z;
+}
+RT_DEV double& ctx_f(const Wf2Space& sp, unsigned slot, int field) { return sp.ctx_d[(size_t)field * sp.ctx_cap + slot]; }
+RT_DEV uint32_t& ctx_u(const Wf2Space& sp, unsigned slot, int field) { return sp.ctx_u[(size_t)field * sp.ctx_cap + slot]; }
+
+// Slots for the lanes of a wave that ask, in lane order, from one counter: one atomic per wave.
+RT_DEV unsigned wave_slots(unsigned* counter, bool want) {
+    const unsigned long long asking = __builtin_amdgcn_ballot_w64(want);
+    if (asking == 0ull) return 0u;
+    const unsigned lane = __lane_id();
+    const int leader = __builtin_ctzll(asking);
+    unsigned base = 0u;
+    if ((int)lane == leader) base = atomicAdd(counter, (unsigned)__builtin_popcountll(asking));
+    base = (unsigned)__shfl((int)base, leader, 64);
+    return base + (unsigned)__builtin_popcountll(asking & ((1ull << lane) - 1ull));
+}
+
+// prepare_computations + pattern colour of every hit of the generation (world.rs:32-43 up to shade_hit's first
+// line); a miss is BLACK, delivered at once (world.rs:41).  PRIMARY: generation 0, items are pixels.
+template <bool STATS, bool PRIMARY>
+__global__ __launch_bounds__(256) void wf2_prepare_kernel(const SceneDev S, Wf2Space sp, RtCameraDesc cam, RowMap rows, int depth,
+                                                          unsigned gen, double* __restrict__ out, RtStats* __restrict__ stats,
+                                                          unsigned* __restrict__ status) {
+    constexpr int CLS = RT_CLASS_NESTED_LEAVES;
+    Ctx<STATS, CLS> cx;
+    cx.status = 0;
+    if constexpr (STATS) {
+#pragma unroll
+        for (int i = 0; i < ST_COUNT; ++i) cx.cnt[i] = 0;
+    }
+    const PixelMap pm = pixel_map(cam, rows);
+    const unsigned n = PRIMARY ? pm.n_items : sp.cnt->n_rays[gen];
+    const unsigned n_round = (n + 63u) & ~63u;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += gridDim.x * blockDim.x) {
+        bool valid = i < n;
+        Ray ray{v3(0.0, 0.0, 0.0), v3(0.0, 0.0, 1.0)};
+        uint32_t parent = 0, remaining = 0;
+        if (valid) {
+            if constexpr (PRIMARY) {
+                unsigned x, k, y;
+                valid = pixel_of_item(cam, rows, pm, i, x, k, y);
+                if (valid) {
+                    ray = ray_for_pixel(cam, x, y);
+                    parent = RT_WF_PIXEL | (k * cam.hsize + x);
+                    remaining = (uint32_t)depth;
+                }
+            } else {
+                const WfItem* it = sp.qd + i;
+                remaining = it->remaining;
+                valid = remaining != RT_WF_EMPTY;
+                if (valid) ray = it->ray, parent = it->parent;
+            }
+        }
+        Best hit{__builtin_inf(), -1};
+        if (valid) {
+            const Wf2Hit h = sp.hits[i];
+            hit.t = h.t, hit.idx = h.idx;
+        }
+        const bool has = valid && hit.idx >= 0;
+        if (valid && !has) wf_deliver(sp.ws.nodes, out, parent, v3(0.0, 0.0, 0.0));
+        const unsigned slot = wave_slots(&sp.cnt->n_hits, has);
+        bool want_n = false;
+        if (has) {
+            const RtShape* __restrict__ sh = S.shapes + hit.idx;
+            const RtMaterial m = S.mats[sh->material];
+            want_n = m.transparency != 0.0 && remaining != 0u;
+            Scratch unused_list;  // prepare_computations touches the list only for n1 / n2, which come later (dead here)
+            Comps c;
+            prepare_computations(S, unused_list, ray, hit, false, c, cx);
+            V3 color = v3(m.color[0], m.color[1], m.color[2]);
+            if (m.pattern >= 0) {
+                unsigned nodes = 0;
+                color = pattern_eval(S.pats, m.pattern, c.object_over_point, nodes);
+                count(cx, ST_PATTERN_NODES, nodes);
+            }
+            ctx_put(sp, slot, CX_OVER, c.over_point);
+            ctx_put(sp, slot, CX_UNDER, c.under_point);
+            ctx_put(sp, slot, CX_EYE, c.eye_v);
+            ctx_put(sp, slot, CX_NORMAL, c.normal_v);
+            ctx_put(sp, slot, CX_REFLECT, c.reflect_v);
+            ctx_put(sp, slot, CX_COLOR, color);
+            ctx_f(sp, slot, CX_T) = hit.t;
+            ctx_f(sp, slot, CX_N1) = 1.0;
+            ctx_f(sp, slot, CX_N2) = 1.0;
+            ctx_u(sp, slot, CU_MAT) = sh->material;
+            ctx_u(sp, slot, CU_PARENT) = parent;
+            ctx_u(sp, slot, CU_REMAINING) = remaining;
+            ctx_u(sp, slot, CU_ITEM) = i;
+        }
+        const unsigned r = wave_slots(&sp.cnt->n_creq, want_n);
+        if (want_n) sp.creq[r] = slot;
+    }
+    flush_stats(cx, stats, status);
+}
+
+// The containers walk (intersection.rs:50-75) of the transparent hits: the sorted world list up to the hit.
+template <bool STATS, bool PRIMARY>
+__global__ __launch_bounds__(64, RT_WAVES_PER_SIMD_WF) void wf2_containers_kernel(const SceneDev S, Wf2Space sp, RtCameraDesc cam, RowMap rows,
+                                                                                  RtStats* __restrict__ stats, unsigned* __restrict__ status) {
+    constexpr int CLS = RT_CLASS_NESTED_LEAVES;
+    Ctx<STATS, CLS> cx;
+    cx.status = 0;
+    if constexpr (STATS) {
+#pragma unroll
+        for (int i = 0; i < ST_COUNT; ++i) cx.cnt[i] = 0;
+    }
+    const PixelMap pm = pixel_map(cam, rows);
+    const unsigned n = sp.cnt->n_creq;
+    for (unsigned r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+        const unsigned slot = sp.creq[r];
+        const unsigned item = ctx_u(sp, slot, CU_ITEM);
+        Ray ray;
+        double unused;
+        wf2_item_ray<PRIMARY ? WF2_PRIMARY : WF2_QUEUE>(S, sp, cam, rows, pm, item, 0u, ray, unused);
+        Scratch W;
+        double n1, n2;
+        containers_pass(S, W, ray, ctx_f(sp, slot, CX_T), n1, n2, cx);
+        ctx_f(sp, slot, CX_N1) = n1;
+        ctx_f(sp, slot, CX_N2) = n2;
+    }
+    flush_stats(cx, stats, status);
+}
+
+RT_DEV void ctx_shade(const SceneDev& S, const Wf2Space& sp, unsigned slot, Shade& sd, uint32_t& remaining) {
+    sd.over = ctx_v3(sp, slot, CX_OVER), sd.under = ctx_v3(sp, slot, CX_UNDER), sd.eye = ctx_v3(sp, slot, CX_EYE);
+    sd.normal = ctx_v3(sp, slot, CX_NORMAL), sd.reflect_v = ctx_v3(sp, slot, CX_REFLECT), sd.color = ctx_v3(sp, slot, CX_COLOR);
+    sd.n1 = ctx_f(sp, slot, CX_N1), sd.n2 = ctx_f(sp, slot, CX_N2);
+    sd.mat = (int)ctx_u(sp, slot, CU_MAT);
+    sd.li = S.n_lights;
+    remaining = ctx_u(sp, slot, CU_REMAINING);
+    const RtMaterial m = S.mats[sd.mat];
+    sd.want_n = (m.transparency != 0.0 && remaining != 0u) ? 1 : 0;
+}
+
+// shade_hit from its light loop on (world.rs:58-82) for every hit of the generation: lighting per light with the
+// feelers' answers, then the children -- into the node pool and the next generation's queue (wf_commit), or, for a
+// hit that has none, the colour straight to whoever waits for it.
+template <bool STATS>
+__global__ __launch_bounds__(256) void wf2_finish_kernel(const SceneDev S, Wf2Space sp, unsigned gen, double* __restrict__ out,
+                                                         RtStats* __restrict__ stats, unsigned* __restrict__ status) {
+    constexpr int CLS = RT_CLASS_NESTED_LEAVES;
+    Ctx<STATS, CLS> cx;
+    cx.status = 0;
+    if constexpr (STATS) {
+#pragma unroll
+        for (int i = 0; i < ST_COUNT; ++i) cx.cnt[i] = 0;
+    }
+    const unsigned n = sp.cnt->n_hits;
+    const unsigned n_round = (n + 63u) & ~63u;
+    for (unsigned slot = blockIdx.x * blockDim.x + threadIdx.x; slot < n_round; slot += gridDim.x * blockDim.x) {
+        const bool active = slot < n;
+        Shade sd;
+        sd.surface = v3(0.0, 0.0, 0.0);
+        sd.over = sd.reflect_v = v3(0.0, 0.0, 0.0);
+        uint32_t remaining = 0, parent = 0;
+        Children ch;
+        ch.do_reflect = ch.do_refract = ch.use_schlick = false;
+        ch.reflectance = 0.0;
+        double reflective = 0.0, transparency = 0.0;
+        bool want = false;
+        if (active) {
+            ctx_shade(S, sp, slot, sd, remaining);
+            parent = ctx_u(sp, slot, CU_PARENT);
+            const RtMaterial m = S.mats[sd.mat];
+            for (unsigned l = 0; l < S.n_lights; ++l) {  // world.rs:58-70, in light order
+                const RtLight light = S.lights[l];
+                const bool occluded = sp.occ[(size_t)l * n + slot] != 0;
+                sd.surface = sd.surface + lighting(m, sd.color, light, sd.over, sd.eye, sd.normal, occluded, cx);
+            }
+            reflective = m.reflective, transparency = m.transparency;
+            shade_children(m, sd, Ray{sd.over, sd.reflect_v}, (int)remaining, ch, cx);
+            want = ch.do_reflect || ch.do_refract;
+        }
+        // a wave's children go to the shard picked by where they come from: 512 consecutive hits
+        const unsigned out_shard = (((unsigned)__builtin_amdgcn_readfirstlane((int)slot) >> RT_WF_CHUNK_SHIFT) * 2654435761u) >> 24;
+        const bool placed = wf_commit(sp.ws, out_shard, gen, want, parent, sd.surface, reflective, transparency, ch, sd.over,
+                                      sd.reflect_v, (int)remaining - 1);
+        if (placed) {
+            if (ch.do_reflect) count(cx, ST_RAY_REFLECT);
+            if (ch.do_refract) count(cx, ST_RAY_REFRACT);
+        } else if (active && !want) {
+            wf_deliver(sp.ws.nodes, out, parent,
+                       combine(sd.surface, v3(0.0, 0.0, 0.0), v3(0.0, 0.0, 0.0), ch.use_schlick, ch.reflectance));
+        }
+        const bool refused = want && !placed;
+        const unsigned r = wave_slots(&sp.cnt->n_overflow, refused);
+        if (refused) {
+            ctx_put(sp, slot, CX_SURFACE, sd.surface);
+            sp.overflow[r] = slot;
+        }
+    }
+    flush_stats(cx, stats, status);
+}
+
+// Hits whose children found no room in the queue or the node pool: the lane keeps the subtree (color_at's frame
+// stack), exactly as world.rs:98-127 recurse.  Capacity costs speed, never the result.
+template <bool STATS>
+__global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void wf2_overflow_kernel(const SceneDev S, Wf2Space sp, double* __restrict__ out,
+                                                                             RtStats* __restrict__ stats, unsigned* __restrict__ status) {
+    constexpr int CLS = RT_CLASS_NESTED_LEAVES;
+    Ctx<STATS, CLS> cx;
+    cx.status = 0;
+    if constexpr (STATS) {
+#pragma unroll
+        for (int i = 0; i < ST_COUNT; ++i) cx.cnt[i] = 0;
+    }
+    const unsigned n = sp.cnt->n_overflow;
+    for (unsigned r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+        const unsigned slot = sp.overflow[r];
+        Shade sd;
+        uint32_t remaining;
+        ctx_shade(S, sp, slot, sd, remaining);
+        sd.surface = ctx_v3(sp, slot, CX_SURFACE);
+        const RtMaterial m = S.mats[sd.mat];
+        Children ch;
+        Ctx<false, CLS> quiet;  // (the Schlick evaluation was counted when the hit was lit)
+        quiet.status = 0;
+        shade_children(m, sd, Ray{sd.over, sd.reflect_v}, (int)remaining, ch, quiet);
+        Scratch W;
+        Frame frames[RT_MAX_DEPTH + 1];
+        V3 child[2] = {v3(0.0, 0.0, 0.0), v3(0.0, 0.0, 0.0)};
+        for (int kind = 0; kind < 2; ++kind) {  // reflected first, then refracted (world.rs:72-73)
+            if (!(kind == 0 ? ch.do_reflect : ch.do_refract)) continue;
+            count(cx, kind == 0 ? ST_RAY_REFLECT : ST_RAY_REFRACT);
+            const Ray ray = kind == 0 ? Ray{sd.over, sd.reflect_v} : ch.refract_ray;
+            child[kind] = color_at(S, W, frames, ray, (int)remaining - 1, cx) * (kind == 0 ? m.reflective : m.transparency);
+        }
+        wf_deliver(sp.ws.nodes, out, ctx_u(sp, slot, CU_PARENT), combine(sd.surface, child[0], child[1], ch.use_schlick, ch.reflectance));
+    }
+    flush_stats(cx, stats, status);
+}
+
+// Generation `gen` is through: its nodes end here (what wf_mark_kernel does), and the rays it queued for generation
+// gen + 1 -- spread over the (shard, octant) sub-slices wf_commit filled -- get their places in the dense queue.
+__global__ __launch_bounds__(RT_WF_SHARDS) void wf2_scan_kernel(Wf2Space sp, unsigned gen) {
+    __shared__ unsigned totals[RT_WF_SHARDS];
+    const unsigned s = threadIdx.x;
+    WfShard& sh = sp.ws.shards[s];
+    const unsigned long long end = (unsigned long long)sh.node_begin[gen] + sh.nodes_asked[gen];
+    sh.node_begin[gen + 1u] = end < sp.ws.node_cap ? (unsigned)end : sp.ws.node_cap;
+    const unsigned sub_cap = sp.ws.q_cap / RT_WF_BINS;
+    unsigned cnt[RT_WF_BINS], total = 0;
+#pragma unroll
+    for (unsigned o = 0; o < RT_WF_BINS; ++o) {
+        const unsigned c = sh.items[(gen + 1u) & 1u][o];
+        cnt[o] = c < sub_cap ? c : sub_cap;
+        total += cnt[o];
+        sh.items[(gen + 1u) & 1u][o] = 0u;  // the generation after next counts here
+    }
+    totals[s] = total;
+    __syncthreads();
+    if (s == 0) {  // 256 values: a serial scan is a microsecond
+        unsigned run = 0;
+        for (unsigned k = 0; k < RT_WF_SHARDS; ++k) {
+            const unsigned t = totals[k];
+            totals[k] = run;
+            run += t;
+        }
+        sp.cnt->n_rays[gen + 1u] = run;
+        sp.cnt->offsets[RT_WF_SHARDS * RT_WF_BINS] = run;
+        sp.cnt->n_hits = 0u, sp.cnt->n_creq = 0u, sp.cnt->n_overflow = 0u;
+    }
+    __syncthreads();
+    unsigned at = totals[s];
+#pragma unroll
+    for (unsigned o = 0; o < RT_WF_BINS; ++o) {
+        sp.cnt->offsets[s * RT_WF_BINS + o] = at;
+        at += cnt[o];
+    }
+}
+__global__ __launch_bounds__(256) void wf2_compact_kernel(Wf2Space sp, unsigned gen) {
+    const unsigned k = blockIdx.x % (RT_WF_SHARDS * RT_WF_BINS), part = blockIdx.x / (RT_WF_SHARDS * RT_WF_BINS);
+    const unsigned parts = gridDim.x / (RT_WF_SHARDS * RT_WF_BINS);
+    const unsigned begin = sp.cnt->offsets[k], count = sp.cnt->offsets[k + 1u] - begin;
+    const unsigned shard = k / RT_WF_BINS, o = k % RT_WF_BINS, sub_cap = sp.ws.q_cap / RT_WF_BINS;
+    const uint4* __restrict__ src = reinterpret_cast<const uint4*>(sp.ws.queue[(gen + 1u) & 1u] + (size_t)shard * sp.ws.q_cap + (size_t)o * sub_cap);
+    uint4* __restrict__ dst = reinterpret_cast<uint4*>(sp.qd + begin);
+    // an item is four 16-byte words: consecutive lanes move consecutive words
+    for (unsigned w = part * 256u + threadIdx.x; w < count * 4u; w += parts * 256u) dst[w] = src[w];
+}
+
+}  // namespace rtk

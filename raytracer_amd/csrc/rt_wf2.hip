@@ -1,0 +1,388 @@
+// rt_wf2.hip -- host side of the kernel pipeline for large scenes (rt_wf2.h): the 4-wide hierarchy built from the
+// scene's skip-link nodes, the workspace, and the launch sequence of one frame.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+#include "rt_host_internal.h"
+#include "rt_wf2.h"
+
+using namespace rtd;
+using namespace rtk;
+
+struct Wf2 {
+    Bvh4Node* d_nodes = nullptr;
+    Wf2Accel accel{};
+    uint32_t n_nodes = 0, stack_need = 0;
+    // workspace, grown to the largest batch asked for; launches on one scene are ordered by the caller
+    Wf2Space sp{};
+    void* blocks[16] = {};
+    size_t batch_pixels = 0, q_items = 0, node_items = 0;
+    int trace_blocks_per_cu[2][3] = {};  // [stats][mode], from the occupancy query
+    int n_cus = 0;
+};
+
+namespace {
+
+// ---- 4-wide hierarchy ------------------------------------------------------------------------------------------
+struct TNode {
+    float lo[3], hi[3];
+    int32_t shape;  // leaf: shape index; inner: -1
+    std::vector<uint32_t> kids;
+};
+
+// The skip-link nodes [k, ...) up to `after` as a sequence of sibling subtrees (an inner node's children are the
+// sequence from k + 1 to its miss link).  False when the links do not nest that way.
+bool parse_seq(const RtSceneDesc& d, int32_t k, int32_t after, std::vector<TNode>& tree, std::vector<uint32_t>& out, int depth) {
+    if (depth > 4096) return false;
+    while (k != after) {
+        if (k < 0 || k >= (int32_t)d.n_bvh_nodes) return false;
+        if (after >= 0 && k > after) return false;
+        const RtBvhNode& nd = d.bvh_nodes[k];
+        TNode t;
+        for (int a = 0; a < 3; ++a) t.lo[a] = nd.bmin[a], t.hi[a] = nd.bmax[a];
+        t.shape = nd.shape;
+        const uint32_t self = (uint32_t)tree.size();
+        tree.push_back(t);
+        if (nd.shape < 0) {
+            std::vector<uint32_t> kids;
+            if (!parse_seq(d, k + 1, nd.miss, tree, kids, depth + 1) || kids.empty()) return false;
+            tree[self].kids = std::move(kids);
+        }
+        out.push_back(self);
+        k = nd.miss;
+    }
+    return true;
+}
+
+double half_area(const TNode& t) {
+    const double x = (double)t.hi[0] - t.lo[0], y = (double)t.hi[1] - t.lo[1], z = (double)t.hi[2] - t.lo[2];
+    if (!(x >= 0.0 && y >= 0.0 && z >= 0.0)) return 0.0;
+    const double a = x * y + y * z + z * x;
+    return std::isfinite(a) ? a : INFINITY;
+}
+
+struct Builder {
+    std::vector<TNode>& tree;
+    std::vector<Bvh4Node> nodes;
+    uint32_t stack_need = 0;
+
+    // at most four subtrees out of `list`: inner ones are opened up (largest first) while the result still fits four;
+    // longer lists are cut into four runs, each under a synthetic inner node
+    std::vector<uint32_t> four(std::vector<uint32_t> list) {
+        while (list.size() > 4) {
+            std::vector<uint32_t> grouped;
+            const size_t n = list.size();
+            for (size_t g = 0; g < 4; ++g) {
+                const size_t a = n * g / 4, b = n * (g + 1) / 4;
+                if (b - a == 1) {
+                    grouped.push_back(list[a]);
+                    continue;
+                }
+                TNode t;
+                for (int ax = 0; ax < 3; ++ax) t.lo[ax] = INFINITY, t.hi[ax] = -INFINITY;
+                t.shape = -1;
+                for (size_t i = a; i < b; ++i) {
+                    for (int ax = 0; ax < 3; ++ax) {
+                        t.lo[ax] = std::fmin(t.lo[ax], tree[list[i]].lo[ax]);
+                        t.hi[ax] = std::fmax(t.hi[ax], tree[list[i]].hi[ax]);
+                    }
+                    t.kids.push_back(list[i]);
+                }
+                grouped.push_back((uint32_t)tree.size());
+                tree.push_back(t);
+            }
+            list = grouped;
+        }
+        for (;;) {
+            int best = -1;
+            double best_area = -1.0;
+            for (size_t i = 0; i < list.size(); ++i) {
+                const TNode& t = tree[list[i]];
+                if (t.shape >= 0 || list.size() - 1 + t.kids.size() > 4) continue;
+                const double a = half_area(t);
+                if (a > best_area) best_area = a, best = (int)i;
+            }
+            if (best < 0) break;
+            const std::vector<uint32_t> kids = tree[list[(size_t)best]].kids;
+            list.erase(list.begin() + best);
+            list.insert(list.end(), kids.begin(), kids.end());
+        }
+        return list;
+    }
+
+    // emits the node whose children are `list` (<= 4 after four()); returns its index and the stack entries a walk
+    // below it can need
+    uint32_t emit(const std::vector<uint32_t>& list_in, uint32_t& need) {
+        const std::vector<uint32_t> list = four(list_in);
+        const uint32_t self = (uint32_t)nodes.size();
+        nodes.emplace_back();
+        Bvh4Node nd;
+        std::memset(&nd, 0, sizeof nd);
+        uint32_t deepest = 0;
+        for (int c = 0; c < 4; ++c) {
+            for (int a = 0; a < 3; ++a) nd.lo[a][c] = INFINITY, nd.hi[a][c] = -INFINITY;
+            nd.child[c] = (int32_t)RT_BVH4_DONE;
+        }
+        for (size_t c = 0; c < list.size(); ++c) {
+            const TNode t = tree[list[c]];
+            for (int a = 0; a < 3; ++a) nd.lo[a][c] = t.lo[a], nd.hi[a][c] = t.hi[a];
+            if (t.shape >= 0) {
+                nd.child[c] = (int32_t)(RT_BVH4_LEAF | (uint32_t)t.shape);
+            } else {
+                uint32_t below = 0;
+                nd.child[c] = (int32_t)emit(t.kids, below);
+                deepest = std::max(deepest, below);
+            }
+        }
+        nodes[self] = nd;
+        need = (uint32_t)list.size() - 1u + deepest;
+        return self;
+    }
+};
+
+template <class K>
+int occupancy(K kernel, int* out) {
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(out, kernel, 64, 0));
+    if (*out < 1) *out = 1;
+    return RT_OK;
+}
+
+#ifndef RT_WF2_QUEUE_PER_PIXEL
+#define RT_WF2_QUEUE_PER_PIXEL 0.75  // queue slots of one generation and node slots of a batch, per pixel of the batch;
+#define RT_WF2_NODES_PER_PIXEL 1.0   // past that a hit keeps its subtree to itself (slower, same result)
+#endif
+#ifndef RT_WF2_BUDGET_MB
+#define RT_WF2_BUDGET_MB 4608  // workspace bound: larger frames are rendered in batches of rows (RT_HIP_WF_BUDGET_MB overrides)
+#endif
+
+size_t budget_bytes() {
+    static const size_t v = [] {
+        const char* e = std::getenv("RT_HIP_WF_BUDGET_MB");
+        const long mb = e && *e ? std::atol(e) : 0;
+        return (size_t)(mb > 0 ? mb : RT_WF2_BUDGET_MB) << 20;
+    }();
+    return v;
+}
+
+struct Plan {
+    size_t q_cap, node_cap;  // per shard
+    size_t qd_cap, ctx_cap, bytes;
+};
+Plan plan_for(size_t items, size_t q_items, size_t node_items, uint32_t n_lights) {
+    Plan p;
+    const size_t qi = q_items ? q_items : (size_t)(RT_WF2_QUEUE_PER_PIXEL * (double)items);
+    const size_t ni = node_items ? node_items : (size_t)(RT_WF2_NODES_PER_PIXEL * (double)items);
+    p.q_cap = (qi + RT_WF_SHARDS - 1) / RT_WF_SHARDS;
+    p.node_cap = (ni + RT_WF_SHARDS - 1) / RT_WF_SHARDS;
+    if (!q_items && p.q_cap < 128) p.q_cap = 128;
+    if (!node_items && p.node_cap < 64) p.node_cap = 64;
+    if (p.node_cap == 0) p.node_cap = 1;
+    p.q_cap = (p.q_cap + RT_WF_BINS - 1) / RT_WF_BINS * RT_WF_BINS;  // a slice is split evenly over the direction octants
+    if (p.q_cap == 0) p.q_cap = RT_WF_BINS;
+    p.qd_cap = p.q_cap * RT_WF_SHARDS;
+    p.ctx_cap = std::max(items, p.qd_cap);
+    p.bytes = 2 * p.qd_cap * sizeof(WfItem) + p.node_cap * RT_WF_SHARDS * sizeof(WfNode) + p.ctx_cap * sizeof(Wf2Hit) +
+              p.ctx_cap * (CX_DOUBLES * sizeof(double) + CU_UINTS * sizeof(uint32_t) + 2 * sizeof(uint32_t) + n_lights);
+    return p;
+}
+
+void free_space(Wf2* w) {
+    for (void*& p : w->blocks) {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+    }
+    std::memset(&w->sp, 0, sizeof w->sp);
+    w->batch_pixels = 0;
+}
+
+int ensure_space(Wf2* w, size_t items, size_t q_items, size_t node_items, uint32_t n_lights) {
+    if (w->sp.cnt && w->batch_pixels >= items && w->q_items == q_items && w->node_items == node_items) return RT_OK;
+    if (w->sp.cnt) {
+        HIP_TRY(hipDeviceSynchronize());  // grow: the old space is idle by contract once the device is
+        free_space(w);
+    }
+    const Plan p = plan_for(items, q_items, node_items, n_lights);
+    if (p.node_cap * RT_WF_SHARDS >= 0x40000000ull || p.qd_cap >= 0x80000000ull || p.ctx_cap >= 0x80000000ull) return RT_ERR_INVALID_ARG;
+    int nb = 0;
+    int rc = RT_OK;
+    auto get = [&](auto** ptr, size_t bytes) {
+        if (rc != RT_OK) return;
+        void* q = nullptr;
+        const hipError_t e = hipMalloc(&q, bytes ? bytes : 16);
+        if (e != hipSuccess) {
+            rc = rth::hip_fail(e, "hipMalloc(kernel pipeline workspace)");
+            return;
+        }
+        w->blocks[nb++] = q;
+        *ptr = reinterpret_cast<std::remove_reference_t<decltype(**ptr)>*>(q);
+    };
+    Wf2Space& s = w->sp;
+    get(&s.ws.queue[0], p.qd_cap * sizeof(WfItem));
+    s.ws.queue[1] = s.ws.queue[0];  // the sliced queue is emptied (compacted) before the next generation fills it
+    get(&s.ws.nodes, p.node_cap * RT_WF_SHARDS * sizeof(WfNode));
+    get(&s.ws.shards, RT_WF_SHARDS * sizeof(WfShard));
+    get(&s.qd, p.qd_cap * sizeof(WfItem));
+    get(&s.hits, p.ctx_cap * sizeof(Wf2Hit));
+    get(&s.ctx_d, p.ctx_cap * CX_DOUBLES * sizeof(double));
+    get(&s.ctx_u, p.ctx_cap * CU_UINTS * sizeof(uint32_t));
+    get(&s.occ, p.ctx_cap * (n_lights ? n_lights : 1u));
+    get(&s.creq, p.ctx_cap * sizeof(uint32_t));
+    get(&s.overflow, p.ctx_cap * sizeof(uint32_t));
+    get(&s.cnt, sizeof(Wf2Counters));
+    if (rc != RT_OK) {
+        (void)hipGetLastError();
+        free_space(w);
+        return rc;
+    }
+    s.ws.cam = nullptr;
+    s.ws.q_cap = (unsigned)p.q_cap, s.ws.node_cap = (unsigned)p.node_cap;
+    s.qd_cap = (unsigned)p.qd_cap, s.ctx_cap = (unsigned)p.ctx_cap;
+    w->batch_pixels = items, w->q_items = q_items, w->node_items = node_items;
+    return RT_OK;
+}
+
+}  // namespace
+
+int rth::wf2_create(const RtSceneDesc& d, uint32_t scene_flags, Wf2** out) {
+    *out = nullptr;
+    // What the pipeline covers: a world-level hierarchy whose leaves are primitives (nested in groups or not), no CSG
+    // node and no shadowless primitive anywhere (those need the sorted world list per ray: the older kernels have it).
+    if (d.world_bvh_root < 0 || (scene_flags & RT_SCENE_HAS_SHADOWLESS) || d.n_csgs != 0 || d.n_lights == 0) return RT_OK;
+    std::vector<TNode> tree;
+    std::vector<uint32_t> top;
+    if (!parse_seq(d, d.world_bvh_root, -1, tree, top, 0) || top.empty()) return RT_OK;
+    for (const TNode& t : tree)
+        if (t.shape >= 0 && RT_KIND(d.shapes[t.shape].kind_flags) > RT_SMOOTH_TRIANGLE) return RT_OK;
+    Wf2* w = new Wf2();
+    Builder b{tree, {}, 0};
+    while (top.size() == 1 && tree[top[0]].shape < 0) top = tree[top[0]].kids;
+    if (top.size() == 1) {
+        w->accel.root = RT_BVH4_LEAF | (uint32_t)tree[top[0]].shape;
+        w->stack_need = 1;
+    } else {
+        uint32_t need = 0;
+        w->accel.root = b.emit(top, need);
+        w->stack_need = need + 1u;  // + the sentinel
+    }
+    if (w->stack_need > RT_WF2_MAX_STACK) {
+        delete w;
+        return RT_OK;
+    }
+    for (int a = 0; a < 3; ++a) w->accel.extent[a] = 0.f;
+    for (const TNode& t : tree)
+        for (int a = 0; a < 3; ++a) {
+            if (std::isfinite(t.lo[a])) w->accel.extent[a] = std::fmax(w->accel.extent[a], std::fabs(t.lo[a]));
+            if (std::isfinite(t.hi[a])) w->accel.extent[a] = std::fmax(w->accel.extent[a], std::fabs(t.hi[a]));
+        }
+    w->accel.has_cands = d.dir_res != 0 && d.n_dir_cands != 0 ? 1u : 0u;
+    w->n_nodes = (uint32_t)b.nodes.size();
+    auto body = [&]() -> int {
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->d_nodes), (b.nodes.size() + 1) * sizeof(Bvh4Node)));
+        if (!b.nodes.empty())
+            HIP_TRY(hipMemcpy(w->d_nodes, b.nodes.data(), b.nodes.size() * sizeof(Bvh4Node), hipMemcpyHostToDevice));
+        w->accel.nodes = w->d_nodes;
+        hipDeviceProp_t prop;
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        HIP_TRY(hipGetDeviceProperties(&prop, dev));
+        w->n_cus = prop.multiProcessorCount;
+        int rc = RT_OK;
+#define RT_OCC(ST, MODE) if (rc == RT_OK) rc = occupancy(wf2_trace_kernel<ST, MODE>, &w->trace_blocks_per_cu[ST ? 1 : 0][MODE]);
+        RT_OCC(false, WF2_PRIMARY) RT_OCC(false, WF2_QUEUE) RT_OCC(false, WF2_SHADOW)
+        RT_OCC(true, WF2_PRIMARY) RT_OCC(true, WF2_QUEUE) RT_OCC(true, WF2_SHADOW)
+#undef RT_OCC
+        return rc;
+    };
+    const int rc = body();
+    if (rc != RT_OK) {
+        rth::wf2_destroy(w);
+        return rc;
+    }
+    *out = w;
+    return RT_OK;
+}
+
+void rth::wf2_destroy(Wf2* w) {
+    if (!w) return;
+    free_space(w);
+    if (w->d_nodes) (void)hipFree(w->d_nodes);
+    delete w;
+}
+
+int rth::wf2_render(const RtScene* scene, const RtCameraDesc* cam, uint32_t depth, const RowMap& rows_in, double* d_out,
+                    hipStream_t stream, RtStats* d_stats) {
+    Wf2* w = scene->wf2;
+    const uint32_t n_lights = scene->dev.n_lights;
+    // rows per batch: whole 8-row tiles, as many as the workspace budget holds
+    const size_t tiles_x = (cam->hsize + 7u) / 8u;
+    const size_t row_items = tiles_x * 64u / 8u;  // items per row of pixels (tiles are 8 rows high)
+    size_t batch_rows = (rows_in.n_local_rows + 7u) / 8u * 8u;
+    if (!scene->wf_q_items && !scene->wf_node_items) {
+        while (batch_rows > 8 && plan_for(batch_rows * row_items, 0, 0, n_lights).bytes > budget_bytes()) {
+            const size_t n_batches = (rows_in.n_local_rows + batch_rows - 1) / batch_rows + 1;
+            batch_rows = ((rows_in.n_local_rows + n_batches - 1) / n_batches + 7u) / 8u * 8u;
+        }
+    }
+    if (batch_rows * row_items >= 0x40000000ull) return RT_ERR_INVALID_ARG;
+    const int rc = ensure_space(w, batch_rows * row_items, scene->wf_q_items, scene->wf_node_items, n_lights);
+    if (rc != RT_OK) return rc;
+    const Wf2Space sp = w->sp;
+    const SceneDev& S = scene->dev;
+    const Wf2Accel A = w->accel;
+    unsigned* status = scene->d_status;
+    const dim3 wide(2048), threads(256);
+    auto go = [&](auto stats_tag) {
+        constexpr bool ST = decltype(stats_tag)::value;
+        const dim3 tgrid[3] = {dim3((unsigned)(w->n_cus * w->trace_blocks_per_cu[ST][0])), dim3((unsigned)(w->n_cus * w->trace_blocks_per_cu[ST][1])),
+                               dim3((unsigned)(w->n_cus * w->trace_blocks_per_cu[ST][2]))};
+        for (uint32_t row0 = 0; row0 < rows_in.n_local_rows; row0 += (uint32_t)batch_rows) {
+            RowMap rows = rows_in;
+            rows.row0 = row0;
+            rows.batch_rows = (uint32_t)std::min<size_t>(batch_rows, rows_in.n_local_rows - row0);
+            (void)hipMemsetAsync(sp.ws.shards, 0, RT_WF_SHARDS * sizeof(WfShard), stream);
+            (void)hipMemsetAsync(sp.cnt, 0, sizeof(Wf2Counters), stream);
+            for (unsigned g = 0; g <= depth; ++g) {
+                if (g == 0) {
+                    if (A.has_cands) hipLaunchKernelGGL((wf2_cands_kernel<ST, WF2_PRIMARY>), wide, threads, 0, stream, S, sp, *cam, rows, g, d_stats, status);
+                    hipLaunchKernelGGL((wf2_trace_kernel<ST, WF2_PRIMARY>), tgrid[0], dim3(64), 0, stream, S, A, sp, *cam, rows, g, d_stats, status);
+                    hipLaunchKernelGGL((wf2_prepare_kernel<ST, true>), wide, threads, 0, stream, S, sp, *cam, rows, (int)depth, g, d_out, d_stats, status);
+                } else {
+                    if (A.has_cands) hipLaunchKernelGGL((wf2_cands_kernel<ST, WF2_QUEUE>), wide, threads, 0, stream, S, sp, *cam, rows, g, d_stats, status);
+                    hipLaunchKernelGGL((wf2_trace_kernel<ST, WF2_QUEUE>), tgrid[1], dim3(64), 0, stream, S, A, sp, *cam, rows, g, d_stats, status);
+                    hipLaunchKernelGGL((wf2_prepare_kernel<ST, false>), wide, threads, 0, stream, S, sp, *cam, rows, (int)depth, g, d_out, d_stats, status);
+                }
+                if (A.has_cands) hipLaunchKernelGGL((wf2_cands_kernel<ST, WF2_SHADOW>), wide, threads, 0, stream, S, sp, *cam, rows, g, d_stats, status);
+                hipLaunchKernelGGL((wf2_trace_kernel<ST, WF2_SHADOW>), tgrid[2], dim3(64), 0, stream, S, A, sp, *cam, rows, g, d_stats, status);
+                if (g < depth && (S.flags & RT_SCENE_RECURSIVE)) {  // only hits with recursion budget left ask for n1 / n2
+                    if (g == 0)
+                        hipLaunchKernelGGL((wf2_containers_kernel<ST, true>), dim3(4096), dim3(64), 0, stream, S, sp, *cam, rows, d_stats, status);
+                    else
+                        hipLaunchKernelGGL((wf2_containers_kernel<ST, false>), dim3(4096), dim3(64), 0, stream, S, sp, *cam, rows, d_stats, status);
+                }
+                hipLaunchKernelGGL((wf2_finish_kernel<ST>), wide, threads, 0, stream, S, sp, g, d_out, d_stats, status);
+                if (g < depth && (S.flags & RT_SCENE_RECURSIVE)) {
+                    hipLaunchKernelGGL((wf2_overflow_kernel<ST>), dim3(4096), dim3(64), 0, stream, S, sp, d_out, d_stats, status);
+                    hipLaunchKernelGGL(wf2_scan_kernel, dim3(1), dim3(RT_WF_SHARDS), 0, stream, sp, g);
+                    hipLaunchKernelGGL(wf2_compact_kernel, dim3(RT_WF_SHARDS * RT_WF_BINS * 2u), threads, 0, stream, sp, g);
+                } else {
+                    break;  // nothing can have been queued
+                }
+            }
+            if (S.flags & RT_SCENE_RECURSIVE)
+                for (unsigned k = depth; k-- > 0;) rth::launch_combine(sp.ws, k, d_out, stream);
+        }
+    };
+    if (d_stats)
+        go(std::true_type{});
+    else
+        go(std::false_type{});
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+const char* rth::wf2_describe() {
+    return "kernel pipeline per generation of rays: wf2_trace_kernel (4-wide f32 hierarchy, persistent waves) for colour rays and "
+           "shadow feelers + wf2_cands / wf2_prepare / wf2_containers / wf2_finish / wf2_overflow / wf2_compact + wf_combine_kernel";
+}

@@ -1,0 +1,125 @@
+"""GPU parity at the sizes BASELINE.json states, without the oracle in between where a reference
+artefact exists:
+
+* the nine render exercises at the goldens' own 2048x1080, quantised on the device, against
+  tests/golden/<scene>.png (the reference's renders, images/png/*.png; canvas.rs:85-90 for the
+  8-bit rule) -- same thresholds and Perturb mask as tests/test_oracle_golden.py;
+* the exercises no other test renders above 512x270, row-sampled against the oracle at 2048x1080;
+* BASELINE.json config 5 at its stated size: 10 000 primitives at 7680x4320 (camera.rs:51-66 over the
+  synthetic scene): one launch of all rows == 8 interleaved row-band shards reassembled, bit for bit;
+  a row subsample against the oracle; the generation-per-launch kernels against the one-launch
+  kernel on a band subset; status clean.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import raytracer_amd as rt
+from conftest import rel_mismatch
+from oracle import orc
+from pngio import read_golden
+
+pytestmark = pytest.mark.gpu
+
+@pytest.mark.parametrize("name", list(rt.EXERCISES))
+def test_gpu_render_matches_golden_png(name):
+    """`camera.render(&world)` at the golden's size on the GPU, 8-bit samples from the device
+    (rt_hip_render_rgb8), against the reference's own render of the same exercise."""
+    world, cam = rt.exercise(name)  # 2048x1080, as exercises/<name>.rs
+    got = cam.render_rgb8(world)
+    want = read_golden(name)
+    assert got.shape == want.shape
+    diff = np.abs(got.astype(int) - want.astype(int)).max(axis=2)
+    considered = np.ones(diff.shape, dtype=bool)
+    if name == "pattern":
+        # Perturb ("parity unpinned": noise::SuperSimplex is not in the reference tree): leave out the pixels
+        # whose camera ray hits the middle sphere (shape 3), found with the GPU probe, grown by one pixel
+        cd = cam.desc()
+        inv = np.array(list(cd.inv)).reshape(4, 4)
+        xs, ys = np.arange(cam.h_size), np.arange(cam.v_size)
+        wx = cd.half_width - (xs + 0.5) * cd.pixel_size
+        wy = cd.half_height - (ys + 0.5) * cd.pixel_size
+        px = np.stack(np.broadcast_arrays(wx[None, :], wy[:, None], -1.0, 1.0), axis=-1) @ inv.T
+        origin = inv @ np.array([0.0, 0.0, 0.0, 1.0])
+        d = px[..., :3] - origin[:3]
+        d /= np.linalg.norm(d, axis=-1, keepdims=True)
+        rays = np.concatenate([np.broadcast_to(origin[:3], d.shape), d], axis=-1).reshape(-1, 6)
+        probe = world.probe(rays).reshape(len(ys), len(xs), 16)
+        perturbed = (probe[..., 0] == 1.0) & (probe[..., 2] == 3.0)
+        assert 0.10 < perturbed.mean() < 0.20  # 333 111 px = 15 %
+        grown = perturbed.copy()
+        grown[1:] |= perturbed[:-1]; grown[:-1] |= perturbed[1:]
+        grown[:, 1:] |= perturbed[:, :-1]; grown[:, :-1] |= perturbed[:, 1:]
+        considered = ~grown
+    n = int(considered.sum())
+    differ = int(((diff > 0) & considered).sum())
+    beyond_lsb = int(((diff > 1) & considered).sum())
+    print(f"{name}: GPU vs golden PNG: {differ}/{n} pixels differ ({beyond_lsb} by more than 1 LSB)")
+    assert differ <= 1e-3 * n
+    assert beyond_lsb <= 16  # isolated seam / edge coin flips
+
+
+def _compare(name, gpu, ref):
+    bad = rel_mismatch(gpu, ref, 1e-9).any(axis=-1)
+    dq = np.abs(orc.quantize(gpu).astype(int) - orc.quantize(ref).astype(int)).max(axis=-1)
+    print(f"{name}: {bad.sum()}/{bad.size} px beyond 1e-9 rel; 8-bit: {(dq > 0).sum()} differ, {(dq > 1).sum()} by >1 LSB; "
+          f"max abs diff {np.abs(gpu - ref).max():.3e}")
+    assert (dq > 1).sum() == 0
+    assert (dq > 0).sum() <= 1e-3 * bad.size
+    assert bad.sum() <= 1e-3 * bad.size
+
+
+@pytest.mark.parametrize("name,step", [("plane", 27), ("scene", 27), ("hexagon", 27), ("cover", 54), ("room", 54)])
+def test_exercise_at_golden_size_rows_match_oracle(name, step):
+    """The exercises the 4096x2160 property test does not cover, at the goldens' 2048x1080: every
+    `step`-th row of the GPU frame against the oracle's render of that row (FP64, 1e-9 relative)."""
+    world, cam = rt.exercise(name)
+    gpu = cam.render(world).pixels
+    first = step // 2
+    ref, _ = orc.OracleWorld(world.describe()).render(cam, rows=(first, cam.v_size, step))
+    _compare(f"{name}-2048x1080-rows", gpu[first::step], ref[first::step])
+
+
+def test_config5_at_stated_size():
+    """BASELINE.json configs[4]: the 10 000-primitive synthetic scene at 7680x4320."""
+    import torch
+    from raytracer_amd import tiling
+    W, H = 7680, 4320
+    world, cam = rt.synthetic(W, H, 10000)
+    scene = rt.DeviceScene(world.flatten())
+    cd = cam.desc()
+    # (a) the frame in one call of all rows == 8 interleaved 16-row-band shards (one per GPU of a node), reassembled
+    full = torch.zeros((H, W, 3), dtype=torch.float64, device="cuda")
+    scene.render_rows(cd, 5, 0, 1, H, H, full.data_ptr())
+    torch.cuda.synchronize()
+    scene.status()  # (d) no list overflow, no NaN distance
+    n_parts, band = 8, tiling.DEFAULT_BAND_ROWS
+    slots = tiling.padded_local_rows(H, n_parts, band)
+    shards = []
+    for part in range(n_parts):
+        buf = torch.zeros((slots, W, 3), dtype=torch.float64, device="cuda")
+        scene.render_rows(cd, 5, part, n_parts, band, tiling.n_local_rows(H, part, n_parts, band), buf.data_ptr())
+        shards.append(buf)
+    torch.cuda.synchronize()
+    scene.status()
+    assert torch.equal(tiling.assemble(shards, H, n_parts, band), full)
+    del shards
+    # (c) the one-launch kernel (every lane keeps its pixel's ray tree) on one of 32 band sets == the same rows of the frame above
+    n_sub = 32
+    sub_rows = tiling.n_local_rows(H, 5, n_sub, band)
+    scene.set_wavefront(0)
+    mono = torch.zeros((tiling.padded_local_rows(H, n_sub, band), W, 3), dtype=torch.float64, device="cuda")
+    scene.render_rows(cd, 5, 5, n_sub, band, sub_rows, mono.data_ptr())
+    torch.cuda.synchronize()
+    scene.status()
+    scene.set_wavefront(-1)
+    rows_of_part = tiling.image_rows(H, 5, n_sub, band)
+    assert (rows_of_part >= 0).all() and len(rows_of_part) == sub_rows
+    assert torch.equal(mono[:sub_rows], full.index_select(0, torch.as_tensor(rows_of_part, device="cuda")))
+    # (b) every 166th row against the oracle
+    step = 166
+    first = step // 2
+    ref, _ = orc.OracleWorld(world.describe()).render(cam, rows=(first, H, step))
+    gpu = full[first::step].cpu().numpy()
+    _compare("synthetic-10k-8K-rows", gpu, ref[first::step])

@@ -187,6 +187,13 @@ def test_generation_per_launch_equals_one_launch(name, width, height):
     for q_items, n_items in ((pixels // 7, pixels), (pixels, pixels // 11), (193, 61)):
         assert np.array_equal(mono, _render_resident(scene, cam, 1, q_items, n_items))
     assert np.array_equal(mono, _render_resident(scene, cam, -1))
+    # mode 2, the kernel pipeline (scenes it does not cover are rendered as in mode 1): same frame, same rays
+    pipe, st_pipe = _render_resident(scene, cam, 2, with_stats=True)
+    assert np.array_equal(mono, pipe)
+    for key in ("rays_primary", "rays_shadow", "rays_reflect", "rays_refract", "hits_shaded", "container_passes", "lightings"):
+        assert st_mono[key] == st_pipe[key], key
+    for q_items, n_items in ((pixels // 7, pixels), (pixels, pixels // 11), (193, 61)):
+        assert np.array_equal(mono, _render_resident(scene, cam, 2, q_items, n_items))
     ref, _ = orc.OracleWorld(world.describe()).render(cam)
     compare(f"{name}-generations", wave, ref)
 
@@ -233,7 +240,32 @@ def test_generations_with_row_bands_and_other_budgets():
         return tiling.assemble(shards, H, n_parts, band).cpu().numpy()
 
     for depth in (0, 1, 2, 5, 8):
-        assert np.array_equal(frame(0, depth), frame(1, depth)), depth
+        one = frame(0, depth)
+        assert np.array_equal(one, frame(1, depth)), depth
+        assert np.array_equal(one, frame(2, depth)), depth
     whole = frame(0, 5)
     for n_parts, band in ((3, 16), (8, 16), (2, 5)):
         assert np.array_equal(frame(1, 5, n_parts, band), whole), (n_parts, band)
+        assert np.array_equal(frame(2, 5, n_parts, band), whole), (n_parts, band)
+
+
+def test_pipeline_in_batches_of_rows():
+    """The kernel pipeline renders frames beyond its workspace budget in batches of rows (RT_HIP_WF_BUDGET_MB):
+    the same frame whatever the batch height."""
+    import subprocess, sys, os
+    code = (
+        "import numpy as np, torch, raytracer_amd as rt\n"
+        "world, cam = rt.synthetic(640, 360, 1500)\n"
+        "scene = rt.DeviceScene(world.flatten())\n"
+        "def f(mode):\n"
+        "    scene.set_wavefront(mode)\n"
+        "    out = torch.zeros((360, 640, 3), dtype=torch.float64, device='cuda')\n"
+        "    scene.render_rows(cam.desc(), 5, 0, 1, 360, 360, out.data_ptr())\n"
+        "    torch.cuda.synchronize(); scene.status(); return out.cpu().numpy()\n"
+        "assert 'pipeline' in scene.pipeline_name(5)\n"
+        "assert np.array_equal(f(0), f(2))\n"
+        "print('ok')\n")
+    env = dict(os.environ, RT_HIP_WF_BUDGET_MB="24")  # 640x360 needs ~105 MB: five batches
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
