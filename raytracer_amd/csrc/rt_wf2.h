@@ -14,7 +14,14 @@
 //                        reaches is tested with the reference's own f64 arithmetic, so no decision changes.
 //   wf2_prepare_kernel   prepare_computations + the pattern colour (intersection.rs:45-99, pattern.rs:76-91) of
 //                        every hit; hits are compacted into shading contexts, one shadow feeler per light each
-//   wf2_containers_kernel  n1 / n2 (intersection.rs:50-75) for the transparent hits only
+//                        A third mode builds the sorted list of the world's intersections up to a transparent hit and
+//                        walks it for n1 / n2 (intersection.rs:50-75).  The reference lists what the whole line meets,
+//                        behind the origin too; an entry pair of a CLOSED primitive (sphere, cube, capped conic) that
+//                        lies wholly before the hit pushes and removes that primitive again and leaves no trace in
+//                        `containers`, so closed primitives are looked for only along the segment from the origin
+//                        to the hit (a closed primitive around the origin has the origin in its box) and only the
+//                        open ones (planes, triangles, uncapped conics), which a line can cross an odd number of
+//                        times, along the whole line -- through a second, small hierarchy over them.
 //   wf2_finish_kernel    lighting per light (primitive.rs:111-151), reflected / refracted children
 //                        (world.rs:98-127, schlick intersection.rs:182-200) into the next generation's queue
 //   wf2_overflow_kernel  hits whose children found no room keep their subtree (color_at's frame stack)
@@ -41,8 +48,11 @@ static_assert(sizeof(Bvh4Node) == 128, "one node = one 128-byte line");
 struct Wf2Accel {
     const Bvh4Node* nodes;
     uint32_t root;       // inner node index, or a leaf / DONE code when the tree is that small
+    uint32_t root_open;  // the same over the OPEN primitives only (planes, triangles, uncapped or unbounded conics): see WF2_CONTAINERS
     float extent[3];     // largest |coordinate| of any finite box, per axis: scales the f32 slack of the box test
     uint32_t has_cands;  // the scene has a direction index
+    uint32_t chunk;      // rays a wave takes from the queue at a time
+    uint32_t refill;     // idle lanes that make a wave go back to the queue
 };
 
 struct Wf2Hit {  // closest hit of one colour ray
@@ -62,7 +72,7 @@ struct Wf2Counters {
     unsigned n_hits;                    // shading contexts of the generation at hand
     unsigned n_creq;                    // ... of which transparent: containers requests
     unsigned n_overflow;
-    unsigned chunk[2 * (RT_WF_LEVELS + 1)];  // next chunk of each trace launch (generation x {colour, shadow})
+    unsigned chunk[3 * (RT_WF_LEVELS + 1)];  // next chunk of each trace launch (generation x {colour, shadow, containers})
     unsigned offsets[RT_WF_SHARDS * RT_WF_BINS + 1];  // compaction: start of each (shard, octant) sub-slice in the dense queue
 };
 
@@ -80,12 +90,12 @@ struct Wf2Space {
 };
 
 #ifndef RT_WF2_CHUNK
-#define RT_WF2_CHUNK 256u  // rays a wave takes from the queue at a time
+#define RT_WF2_CHUNK 64u   // rays a wave takes from the queue at a time (RT_HIP_WF2_CHUNK in the environment: studies)
 #endif
 #ifndef RT_WF2_REFILL
-#define RT_WF2_REFILL 16   // idle lanes that make a wave go back to the queue
+#define RT_WF2_REFILL 64u  // idle lanes that make a wave go back to the queue (RT_HIP_WF2_REFILL); measured: partial refills (8-32) cost more than the idle lanes they fill (10k scene 33.0-33.4 ms against 31.6)
 #endif
-enum { WF2_PRIMARY = 0, WF2_QUEUE = 1, WF2_SHADOW = 2 };
+enum { WF2_PRIMARY = 0, WF2_QUEUE = 1, WF2_SHADOW = 2, WF2_CONTAINERS = 3 };
 
 // Item i of generation 0 = one pixel, tiles of 8x8 in row-major tile order (neighbouring rays to one wave).
 struct PixelMap {
@@ -139,6 +149,18 @@ RT_DEV bool wf2_item_ray(const SceneDev& S, const Wf2Space& sp, const RtCameraDe
     }
 }
 
+// ---- shading contexts -----------------------------------------------------------------------------------------
+RT_DEV V3 ctx_v3(const Wf2Space& sp, unsigned slot, int field) {
+    const double* p = sp.ctx_d + (size_t)field * sp.ctx_cap + slot;
+    return v3(p[0], p[sp.ctx_cap], p[2 * (size_t)sp.ctx_cap]);
+}
+RT_DEV void ctx_put(const Wf2Space& sp, unsigned slot, int field, V3 v) {
+    double* p = sp.ctx_d + (size_t)field * sp.ctx_cap + slot;
+    p[0] = v.x, p[sp.ctx_cap] = v.y, p[2 * (size_t)sp.ctx_cap] = v.z;
+}
+RT_DEV double& ctx_f(const Wf2Space& sp, unsigned slot, int field) { return sp.ctx_d[(size_t)field * sp.ctx_cap + slot]; }
+RT_DEV uint32_t& ctx_u(const Wf2Space& sp, unsigned slot, int field) { return sp.ctx_u[(size_t)field * sp.ctx_cap + slot]; }
+
 // ---- the f32 side of a ray: conservative slab tests ------------------------------------------------------------
 // t_lo(axis, child) = lo * inv + cl, t_hi = hi * inv + ch with cl / ch = -o * inv shifted outward by the slack
 // K = |inv| * 2^-20 * (|o| + extent): every rounding of the f32 evaluation (o and inv rounded to f32, the product-sum,
@@ -172,8 +194,9 @@ struct Walk {
 
 // One step of the walk at an inner node: the four child boxes against the ray segment [0, t_far]; the nearest
 // child met becomes the node at hand, the others go on the stack.
+// (t_near = 0 for a ray; the containers walk also wants what lies behind the origin: a negative t_near, or -inf.)
 template <bool STATS, int FLAT>
-RT_DEV void walk_step(const Wf2Accel& A, const RayF32& f, float t_far, Walk& w, uint32_t* lds_stack, uint32_t* deep,
+RT_DEV void walk_step(const Wf2Accel& A, const RayF32& f, float t_near, float t_far, Walk& w, uint32_t* lds_stack, uint32_t* deep,
                       Ctx<STATS, FLAT>& cx) {
     const Bvh4Node* __restrict__ nd = A.nodes + w.cur;
     const float4* __restrict__ q = reinterpret_cast<const float4*>(nd);
@@ -194,7 +217,7 @@ RT_DEV void walk_step(const Wf2Accel& A, const RayF32& f, float t_far, Walk& w, 
         const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
         const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
         // (negated comparisons: a NaN anywhere lets the box through, as the f64 walk does)
-        const bool met = kid[c] != RT_BVH4_DONE && !(tn > tf) && !(tf < 0.f) && !(tn > t_far);
+        const bool met = kid[c] != RT_BVH4_DONE && !(tn > tf) && !(tf < t_near) && !(tn > t_far);
         if (met) {
             uint32_t other = kid[c];
             if (!have || tn < t_next) {
@@ -278,6 +301,59 @@ RT_DEV bool wf2_leaf(const SceneDev& S, int s, const Ray& world_ray, double limi
     return false;
 }
 
+// The sorted hit list of one lane (stands for BTreeSet<Intersection>; see list_insert) and the containers set.
+struct LaneList {
+    double lt[RT_LIST_CAP];
+    uint32_t lid[RT_LIST_CAP];
+    uint32_t ct[RT_LIST_CAP];
+    RT_DEV double& LT(int i) { return lt[i]; }
+    RT_DEV uint32_t& LID(int i) { return lid[i]; }
+    RT_DEV uint32_t& CT(int i) { return ct[i]; }
+    RT_DEV int cap() const { return RT_LIST_CAP; }
+};
+// wf2_leaf for World::intersections as a sorted list cut at t <= bound (world_list): the primitive's surviving hits are
+// inserted with BTreeSet::append's tie rule.  Returns the new length.
+template <bool STATS, int FLAT>
+RT_DEV int wf2_leaf_list(const SceneDev& S, LaneList& W, int top, int s, const Ray& world_ray, double bound, Ctx<STATS, FLAT>& cx) {
+    const RtShape* __restrict__ sh = S.shapes + s;
+    const unsigned kf = sh->kind_flags;
+    const int parent = sh->parent;
+    Ray at = world_ray;
+    int chain[RT_STACK];
+    int n = 0;
+    if (parent >= 0) {
+        n = ancestor_chain(S, parent, chain);
+        for (int q = n - 1; q >= 0; --q) {
+            at = transform_ray(S.shapes[chain[q]].inv, at);
+            count(cx, ST_RAY_XFORM);
+        }
+    }
+    PrimHits h;
+    prim_intersect(S, sh, kf, at, h, cx);
+    bool useful = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) useful = useful || (((h.keep >> k) & 1u) && h.t[k] <= bound);
+    if (!useful) return top;
+    Ray r = world_ray;
+    for (int q = n - 1; q >= 0; --q) {
+        const RtShape* __restrict__ g = S.shapes + chain[q];
+        r = transform_ray(g->inv, r);
+        if (RT_KIND(g->kind_flags) == RT_GROUP) {
+            const RtGroup* __restrict__ gg = S.groups + g->param;
+            count(cx, ST_GATES);
+            if (!(gg->n_children != 0u && box_intersects(gg->bmin, gg->bmax, r))) return top;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (((h.keep >> k) & 1u) && h.t[k] <= bound) {
+            top = list_insert(W, 0, top, h.t[k], (uint32_t)s, cx.status);
+            count(cx, ST_LIST_ENTRIES);
+        }
+    }
+    return top;
+}
+
 // Direction-index candidates of one ray, evaluated like the older kernels evaluate them (cand_next + process_leaf).
 template <bool SHADOW, bool STATS, int FLAT>
 RT_DEV bool wf2_candidates(const SceneDev& S, const Ray& ray, double limit, Best& best, Ctx<STATS, FLAT>& cx) {
@@ -336,6 +412,7 @@ __global__ __launch_bounds__(64, RT_WF2_TRACE_WAVES) void wf2_trace_kernel(const
                                                        unsigned gen, RtStats* __restrict__ stats, unsigned* __restrict__ status) {
     constexpr int CLS = RT_CLASS_NESTED_LEAVES;
     constexpr bool SHADOW = MODE == WF2_SHADOW;
+    constexpr bool LIST = MODE == WF2_CONTAINERS;  // n1 / n2 of the transparent hits: the sorted world list up to the hit
     __shared__ uint32_t lds_stack_all[RT_WF2_LDS_STACK * 64];
     uint32_t* lds_stack = lds_stack_all + threadIdx.x;
     uint32_t deep[RT_WF2_MAX_STACK - RT_WF2_LDS_STACK];
@@ -347,8 +424,12 @@ __global__ __launch_bounds__(64, RT_WF2_TRACE_WAVES) void wf2_trace_kernel(const
     }
     const PixelMap pm = pixel_map(cam, rows);
     const unsigned n_hits = SHADOW ? sp.cnt->n_hits : 0u;
-    const unsigned n = MODE == WF2_PRIMARY ? pm.n_items : (MODE == WF2_QUEUE ? sp.cnt->n_rays[gen] : n_hits * S.n_lights);
-    unsigned* chunk_counter = &sp.cnt->chunk[2u * gen + (SHADOW ? 1u : 0u)];
+    const unsigned n = MODE == WF2_PRIMARY ? pm.n_items
+                       : (MODE == WF2_QUEUE ? sp.cnt->n_rays[gen] : (LIST ? sp.cnt->n_creq : n_hits * S.n_lights));
+    unsigned* chunk_counter = &sp.cnt->chunk[3u * gen + (SHADOW ? 1u : (LIST ? 2u : 0u))];
+    typename std::conditional<LIST, LaneList, int>::type W;
+    int top = 0;       // LIST: entries in W
+    unsigned slot = 0;  // LIST: the hit's shading context
     const unsigned lane = threadIdx.x;
     const unsigned long long below = (1ull << lane) - 1ull;
     unsigned chunk_next = 0, chunk_end = 0;  // wave-uniform
@@ -360,20 +441,21 @@ __global__ __launch_bounds__(64, RT_WF2_TRACE_WAVES) void wf2_trace_kernel(const
     Best best{__builtin_inf(), -1};
     double limit = 0.0;
     bool found = false;
-    float t_far = 0.f;
+    float t_far = 0.f, t_near = 0.f;
+    bool second_walk = false;  // LIST: the walk over the open primitives is still to come
     Walk w{RT_BVH4_DONE, 0};
     for (;;) {
         // ---- refill: idle lanes take the next rays of the wave's chunk
         const unsigned long long idle = __builtin_amdgcn_ballot_w64(!busy);
         const int n_idle = __builtin_popcountll(idle);
-        if (n_idle == 64 || (n_idle >= RT_WF2_REFILL && !dry)) {
+        if (n_idle == 64 || (n_idle >= (int)A.refill && !dry)) {
             if (chunk_next >= chunk_end && !dry) {
                 unsigned c = 0;
-                if (lane == 0) c = atomicAdd(chunk_counter, RT_WF2_CHUNK);
+                if (lane == 0) c = atomicAdd(chunk_counter, A.chunk);
                 c = (unsigned)__builtin_amdgcn_readfirstlane((int)c);
                 if (c < n) {
                     chunk_next = c;
-                    chunk_end = c + RT_WF2_CHUNK < n ? c + RT_WF2_CHUNK : n;
+                    chunk_end = c + A.chunk < n ? c + A.chunk : n;
                 } else {
                     dry = true;
                 }
@@ -386,22 +468,49 @@ __global__ __launch_bounds__(64, RT_WF2_TRACE_WAVES) void wf2_trace_kernel(const
                     busy = true;
                     best.t = __builtin_inf(), best.idx = -1;
                     found = false;
-                    const bool valid = wf2_item_ray<MODE>(S, sp, cam, rows, pm, item, n_hits, ray, limit);
-                    if (A.has_cands) {  // what the direction index already found for this ray
-                        if constexpr (SHADOW) {
-                            found = sp.occ[item] != 0;
-                        } else {
-                            const Wf2Hit h0 = sp.hits[item];
-                            best.t = h0.t, best.idx = h0.idx;
+                    bool valid;
+                    if constexpr (LIST) {
+                        slot = sp.creq[item];
+                        const unsigned of = ctx_u(sp, slot, CU_ITEM);
+                        valid = gen == 0u ? wf2_item_ray<WF2_PRIMARY>(S, sp, cam, rows, pm, of, 0u, ray, limit)
+                                          : wf2_item_ray<WF2_QUEUE>(S, sp, cam, rows, pm, of, 0u, ray, limit);
+                        count(cx, ST_CONTAINER_PASSES);
+                        limit = containers_bound(ctx_f(sp, slot, CX_T));  // the list is cut here
+                        top = 0;
+                        if (A.has_cands) {  // the direction index's candidates first, as world_list has them
+                            CandIter it;
+                            cand_begin(S, ray, it);
+                            const V3 d = ray.d;
+                            while (it.k < it.e) {
+                                const RtDirCand* __restrict__ c = S.dir_cands + (it.scan_all ? it.k : S.dir_entries[it.k]);
+                                ++it.k;
+                                const double a = c->q[0] * d.x * d.x + c->q[1] * d.y * d.y + c->q[2] * d.z * d.z +
+                                                 2.0 * (c->q[3] * d.x * d.y + c->q[4] * d.x * d.z + c->q[5] * d.y * d.z);
+                                if (fabs(a) <= c->thr) top = wf2_leaf_list(S, W, top, (int)c->visit, ray, limit, cx);
+                            }
+                        }
+                    } else {
+                        valid = wf2_item_ray<MODE>(S, sp, cam, rows, pm, item, n_hits, ray, limit);
+                        if (A.has_cands) {  // what the direction index already found for this ray
+                            if constexpr (SHADOW) {
+                                found = sp.occ[item] != 0;
+                            } else {
+                                const Wf2Hit h0 = sp.hits[item];
+                                best.t = h0.t, best.idx = h0.idx;
+                            }
                         }
                     }
                     ray_f32(ray, A.extent, f);
-                    t_far = SHADOW ? f32_up(limit) : f32_up(best.t);
+                    t_far = (SHADOW || LIST) ? f32_up(limit) : f32_up(best.t);
+                    // LIST: what the containers walk can read of the list (see below) is found by two walks: everything that
+                    // meets the segment from just behind the origin to the cut, then the open primitives along the whole line
+                    t_near = LIST ? -1e-2f : 0.f;
+                    second_walk = LIST;
                     lds_stack[0] = RT_BVH4_DONE;
                     w.sp = 1;
                     w.cur = (valid && !found) ? A.root : RT_BVH4_DONE;
                     // (reflected / refracted rays are counted where they are queued, as in wf_level_kernel)
-                    if (valid && MODE != WF2_QUEUE) count(cx, SHADOW ? ST_RAY_SHADOW : ST_RAY_PRIMARY);
+                    if (valid && (MODE == WF2_PRIMARY || SHADOW)) count(cx, SHADOW ? ST_RAY_SHADOW : ST_RAY_PRIMARY);
                 }
                 chunk_next += (unsigned)n_idle < avail ? (unsigned)n_idle : avail;
             } else if (n_idle == 64) {
@@ -409,12 +518,18 @@ __global__ __launch_bounds__(64, RT_WF2_TRACE_WAVES) void wf2_trace_kernel(const
             }
         }
         // ---- box tests only, until every busy lane holds a leaf or is through
-        while (busy && w.cur < RT_BVH4_DONE) walk_step(A, f, t_far, w, lds_stack, deep, cx);
+        while (busy && w.cur < RT_BVH4_DONE) walk_step(A, f, t_near, t_far, w, lds_stack, deep, cx);
         // ---- leaves
         if (busy && (w.cur & RT_BVH4_LEAF)) {
             const int s = (int)(w.cur & ~RT_BVH4_LEAF);
-            const bool hit_shadow = wf2_leaf<SHADOW>(S, s, ray, limit, best, cx);
-            if (SHADOW) {
+            bool hit_shadow = false;
+            if constexpr (LIST)
+                top = wf2_leaf_list(S, W, top, s, ray, limit, cx);
+            else
+                hit_shadow = wf2_leaf<SHADOW>(S, s, ray, limit, best, cx);
+            if (LIST) {
+                walk_pop(w, lds_stack, deep);
+            } else if (SHADOW) {
                 if (hit_shadow) {
                     found = true;
                     w.cur = RT_BVH4_DONE;
@@ -427,8 +542,19 @@ __global__ __launch_bounds__(64, RT_WF2_TRACE_WAVES) void wf2_trace_kernel(const
             }
         }
         // ---- rays that are through
+        if (LIST && busy && w.cur == RT_BVH4_DONE && second_walk) {
+            second_walk = false;
+            t_near = -__builtin_inff();
+            w.sp = 1;
+            w.cur = A.root_open;
+        }
         if (busy && w.cur == RT_BVH4_DONE) {
-            if constexpr (SHADOW) {
+            if constexpr (LIST) {
+                double n1, n2;
+                containers_walk(S, W, top, ctx_f(sp, slot, CX_T), n1, n2, cx);
+                ctx_f(sp, slot, CX_N1) = n1;
+                ctx_f(sp, slot, CX_N2) = n2;
+            } else if constexpr (SHADOW) {
                 sp.occ[item] = found ? 1 : 0;
             } else {
                 Wf2Hit h;
@@ -441,18 +567,6 @@ __global__ __launch_bounds__(64, RT_WF2_TRACE_WAVES) void wf2_trace_kernel(const
     flush_stats(cx, stats, status);
 }
 
-
-// ---- shading contexts -----------------------------------------------------------------------------------------
-RT_DEV V3 ctx_v3(const Wf2Space& sp, unsigned slot, int field) {
-    const double* p = sp.ctx_d + (size_t)field * sp.ctx_cap + slot;
-    return v3(p[0], p[sp.ctx_cap], p[2 * (size_t)sp.ctx_cap]);
-}
-RT_DEV void ctx_put(const Wf2Space& sp, unsigned slot, int field, V3 v) {
-    double* p = sp.ctx_d + (size_t)field * sp.ctx_cap + slot;
-    p[0] = v.x, p[sp.ctx_cap] = v.y, p[2 * (size_t)sp.ctx_cap] = v.z;
-}
-RT_DEV double& ctx_f(const Wf2Space& sp, unsigned slot, int field) { return sp.ctx_d[(size_t)field * sp.ctx_cap + slot]; }
-RT_DEV uint32_t& ctx_u(const Wf2Space& sp, unsigned slot, int field) { return sp.ctx_u[(size_t)field * sp.ctx_cap + slot]; }
 
 // Slots for the lanes of a wave that ask, in lane order, from one counter: one atomic per wave.
 RT_DEV unsigned wave_slots(unsigned* counter, bool want) {
@@ -544,34 +658,6 @@ __global__ __launch_bounds__(256) void wf2_prepare_kernel(const SceneDev S, Wf2S
     flush_stats(cx, stats, status);
 }
 
-// The containers walk (intersection.rs:50-75) of the transparent hits: the sorted world list up to the hit.
-template <bool STATS, bool PRIMARY>
-__global__ __launch_bounds__(64, RT_WAVES_PER_SIMD_WF) void wf2_containers_kernel(const SceneDev S, Wf2Space sp, RtCameraDesc cam, RowMap rows,
-                                                                                  RtStats* __restrict__ stats, unsigned* __restrict__ status) {
-    constexpr int CLS = RT_CLASS_NESTED_LEAVES;
-    Ctx<STATS, CLS> cx;
-    cx.status = 0;
-    if constexpr (STATS) {
-#pragma unroll
-        for (int i = 0; i < ST_COUNT; ++i) cx.cnt[i] = 0;
-    }
-    const PixelMap pm = pixel_map(cam, rows);
-    const unsigned n = sp.cnt->n_creq;
-    for (unsigned r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
-        const unsigned slot = sp.creq[r];
-        const unsigned item = ctx_u(sp, slot, CU_ITEM);
-        Ray ray;
-        double unused;
-        wf2_item_ray<PRIMARY ? WF2_PRIMARY : WF2_QUEUE>(S, sp, cam, rows, pm, item, 0u, ray, unused);
-        Scratch W;
-        double n1, n2;
-        containers_pass(S, W, ray, ctx_f(sp, slot, CX_T), n1, n2, cx);
-        ctx_f(sp, slot, CX_N1) = n1;
-        ctx_f(sp, slot, CX_N2) = n2;
-    }
-    flush_stats(cx, stats, status);
-}
-
 RT_DEV void ctx_shade(const SceneDev& S, const Wf2Space& sp, unsigned slot, Shade& sd, uint32_t& remaining) {
     sd.over = ctx_v3(sp, slot, CX_OVER), sd.under = ctx_v3(sp, slot, CX_UNDER), sd.eye = ctx_v3(sp, slot, CX_EYE);
     sd.normal = ctx_v3(sp, slot, CX_NORMAL), sd.reflect_v = ctx_v3(sp, slot, CX_REFLECT), sd.color = ctx_v3(sp, slot, CX_COLOR);
@@ -583,12 +669,67 @@ RT_DEV void ctx_shade(const SceneDev& S, const Wf2Space& sp, unsigned slot, Shad
     sd.want_n = (m.transparency != 0.0 && remaining != 0u) ? 1 : 0;
 }
 
+// wf_commit for the pipeline: a node per asking lane and its child rays into the shard's slice of the sliced queue,
+// the wave's reflected rays first, then its refracted ones; two atomics per wave.  Every lane of the wave calls it.
+// Returns false for a lane whose request found no room (its pieces that did fit are blanked).
+RT_DEV bool wf2_commit(const WfSpace& ws, unsigned shard, unsigned level, bool want, uint32_t parent, V3 surface,
+                       double reflective, double transparency, const Children& ch, V3 reflect_o, V3 reflect_d,
+                       int remaining_children) {
+    const unsigned long long asking = __builtin_amdgcn_ballot_w64(want);
+    if (asking == 0ull) return false;
+    const unsigned lane = __lane_id();
+    const unsigned long long below = (1ull << lane) - 1ull;
+    WfShard& sh = ws.shards[shard];
+    const bool has0 = want && ch.do_reflect, has1 = want && ch.do_refract;
+    const unsigned long long m0 = __builtin_amdgcn_ballot_w64(has0), m1 = __builtin_amdgcn_ballot_w64(has1);
+    const unsigned n0 = (unsigned)__builtin_popcountll(m0), n1 = (unsigned)__builtin_popcountll(m1);
+    const int leader = __builtin_ctzll(asking);
+    unsigned base_nodes = 0u, base_items = 0u;
+    if ((int)lane == leader) {
+        base_nodes = atomicAdd(&sh.nodes_asked[level], (unsigned)__builtin_popcountll(asking));
+        base_items = atomicAdd(&sh.items[(level + 1u) & 1u][0], n0 + n1);
+    }
+    base_nodes = (unsigned)__shfl((int)base_nodes, leader, 64);
+    base_items = (unsigned)__shfl((int)base_items, leader, 64);
+    if (!want) return false;
+    const unsigned long long ni = (unsigned long long)sh.node_begin[level] + base_nodes + (unsigned)__builtin_popcountll(asking & below);
+    const unsigned long long s0 = (unsigned long long)base_items + (unsigned)__builtin_popcountll(m0 & below);
+    const unsigned long long s1 = (unsigned long long)base_items + n0 + (unsigned)__builtin_popcountll(m1 & below);
+    const bool fit0 = !has0 || s0 < ws.q_cap, fit1 = !has1 || s1 < ws.q_cap;
+    WfItem* __restrict__ q = ws.queue[(level + 1u) & 1u] + (size_t)shard * ws.q_cap;
+    WfNode* __restrict__ nodes = ws.nodes + (size_t)shard * ws.node_cap;
+    if (!(ni < ws.node_cap && fit0 && fit1)) {
+        if (ni < ws.node_cap) nodes[ni].flags = WF_DEAD;
+        if (has0 && fit0) q[s0].remaining = RT_WF_EMPTY;
+        if (has1 && fit1) q[s1].remaining = RT_WF_EMPTY;
+        return false;
+    }
+    WfNode& n = nodes[ni];
+    n.surface = surface;
+    n.child[0] = v3(0.0, 0.0, 0.0);
+    n.child[1] = v3(0.0, 0.0, 0.0);
+    n.reflective = reflective, n.transparency = transparency, n.reflectance = ch.reflectance;
+    n.parent = parent;
+    n.flags = (ch.use_schlick ? WF_USE_SCHLICK : 0u) | (ch.do_reflect ? WF_HAS_REFLECT : 0u) | (ch.do_refract ? WF_HAS_REFRACT : 0u);
+    const uint32_t global_node = (uint32_t)((size_t)shard * ws.node_cap + ni);
+    if (has0) {
+        WfItem& it = q[s0];
+        it.ray = Ray{reflect_o, reflect_d}, it.parent = global_node << 1, it.remaining = (uint32_t)remaining_children;
+    }
+    if (has1) {
+        WfItem& it = q[s1];
+        it.ray = ch.refract_ray, it.parent = (global_node << 1) | 1u, it.remaining = (uint32_t)remaining_children;
+    }
+    return true;
+}
+
 // shade_hit from its light loop on (world.rs:58-82) for every hit of the generation: lighting per light with the
 // feelers' answers, then the children -- into the node pool and the next generation's queue (wf_commit), or, for a
 // hit that has none, the colour straight to whoever waits for it.
 template <bool STATS>
-__global__ __launch_bounds__(256) void wf2_finish_kernel(const SceneDev S, Wf2Space sp, unsigned gen, double* __restrict__ out,
-                                                         RtStats* __restrict__ stats, unsigned* __restrict__ status) {
+__global__ __launch_bounds__(256) void wf2_finish_kernel(const SceneDev S, Wf2Space sp, unsigned gen, unsigned stretch_shift,
+                                                         double* __restrict__ out, RtStats* __restrict__ stats,
+                                                         unsigned* __restrict__ status) {
     constexpr int CLS = RT_CLASS_NESTED_LEAVES;
     Ctx<STATS, CLS> cx;
     cx.status = 0;
@@ -622,9 +763,9 @@ __global__ __launch_bounds__(256) void wf2_finish_kernel(const SceneDev S, Wf2Sp
             shade_children(m, sd, Ray{sd.over, sd.reflect_v}, (int)remaining, ch, cx);
             want = ch.do_reflect || ch.do_refract;
         }
-        // a wave's children go to the shard picked by where they come from: 512 consecutive hits
-        const unsigned out_shard = (((unsigned)__builtin_amdgcn_readfirstlane((int)slot) >> RT_WF_CHUNK_SHIFT) * 2654435761u) >> 24;
-        const bool placed = wf_commit(sp.ws, out_shard, gen, want, parent, sd.surface, reflective, transparency, ch, sd.over,
+        // a wave's children go to the shard picked by where they come from: a stretch of consecutive hits
+        const unsigned out_shard = (((unsigned)__builtin_amdgcn_readfirstlane((int)slot) >> stretch_shift) * 2654435761u) >> 24;
+        const bool placed = wf2_commit(sp.ws, out_shard, gen, want, parent, sd.surface, reflective, transparency, ch, sd.over,
                                       sd.reflect_v, (int)remaining - 1);
         if (placed) {
             if (ch.do_reflect) count(cx, ST_RAY_REFLECT);
@@ -682,52 +823,53 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void wf2_overflow_kernel(con
 }
 
 // Generation `gen` is through: its nodes end here (what wf_mark_kernel does), and the rays it queued for generation
-// gen + 1 -- spread over the (shard, octant) sub-slices wf_commit filled -- get their places in the dense queue.
+// gen + 1 -- one slice of the sliced queue per shard, filled by wf2_commit -- get their places in the dense queue.
 __global__ __launch_bounds__(RT_WF_SHARDS) void wf2_scan_kernel(Wf2Space sp, unsigned gen) {
     __shared__ unsigned totals[RT_WF_SHARDS];
     const unsigned s = threadIdx.x;
     WfShard& sh = sp.ws.shards[s];
     const unsigned long long end = (unsigned long long)sh.node_begin[gen] + sh.nodes_asked[gen];
     sh.node_begin[gen + 1u] = end < sp.ws.node_cap ? (unsigned)end : sp.ws.node_cap;
-    const unsigned sub_cap = sp.ws.q_cap / RT_WF_BINS;
-    unsigned cnt[RT_WF_BINS], total = 0;
-#pragma unroll
-    for (unsigned o = 0; o < RT_WF_BINS; ++o) {
-        const unsigned c = sh.items[(gen + 1u) & 1u][o];
-        cnt[o] = c < sub_cap ? c : sub_cap;
-        total += cnt[o];
-        sh.items[(gen + 1u) & 1u][o] = 0u;  // the generation after next counts here
-    }
-    totals[s] = total;
+    const unsigned asked = sh.items[(gen + 1u) & 1u][0];
+    sh.items[(gen + 1u) & 1u][0] = 0u;  // the generation after next counts here
+    totals[s] = asked < sp.ws.q_cap ? asked : sp.ws.q_cap;
     __syncthreads();
     if (s == 0) {  // 256 values: a serial scan is a microsecond
         unsigned run = 0;
         for (unsigned k = 0; k < RT_WF_SHARDS; ++k) {
-            const unsigned t = totals[k];
-            totals[k] = run;
-            run += t;
+            sp.cnt->offsets[k] = run;
+            run += totals[k];
         }
+        sp.cnt->offsets[RT_WF_SHARDS] = run;
         sp.cnt->n_rays[gen + 1u] = run;
-        sp.cnt->offsets[RT_WF_SHARDS * RT_WF_BINS] = run;
         sp.cnt->n_hits = 0u, sp.cnt->n_creq = 0u, sp.cnt->n_overflow = 0u;
     }
-    __syncthreads();
-    unsigned at = totals[s];
-#pragma unroll
-    for (unsigned o = 0; o < RT_WF_BINS; ++o) {
-        sp.cnt->offsets[s * RT_WF_BINS + o] = at;
-        at += cnt[o];
-    }
 }
+// One block per shard: the shard's slice into the dense queue, sorted by the octant of the ray's direction (rays that
+// start near each other -- one shard = a few 512-hit stretches of the parent generation -- and point the same way walk
+// the same part of the hierarchy).
 __global__ __launch_bounds__(256) void wf2_compact_kernel(Wf2Space sp, unsigned gen) {
-    const unsigned k = blockIdx.x % (RT_WF_SHARDS * RT_WF_BINS), part = blockIdx.x / (RT_WF_SHARDS * RT_WF_BINS);
-    const unsigned parts = gridDim.x / (RT_WF_SHARDS * RT_WF_BINS);
-    const unsigned begin = sp.cnt->offsets[k], count = sp.cnt->offsets[k + 1u] - begin;
-    const unsigned shard = k / RT_WF_BINS, o = k % RT_WF_BINS, sub_cap = sp.ws.q_cap / RT_WF_BINS;
-    const uint4* __restrict__ src = reinterpret_cast<const uint4*>(sp.ws.queue[(gen + 1u) & 1u] + (size_t)shard * sp.ws.q_cap + (size_t)o * sub_cap);
-    uint4* __restrict__ dst = reinterpret_cast<uint4*>(sp.qd + begin);
-    // an item is four 16-byte words: consecutive lanes move consecutive words
-    for (unsigned w = part * 256u + threadIdx.x; w < count * 4u; w += parts * 256u) dst[w] = src[w];
+    __shared__ unsigned count[RT_WF_BINS], start[RT_WF_BINS];
+    const unsigned shard = blockIdx.x;
+    const unsigned begin = sp.cnt->offsets[shard], n = sp.cnt->offsets[shard + 1u] - begin;
+    const WfItem* __restrict__ src = sp.ws.queue[(gen + 1u) & 1u] + (size_t)shard * sp.ws.q_cap;
+    WfItem* __restrict__ dst = sp.qd + begin;
+    if (threadIdx.x < RT_WF_BINS) count[threadIdx.x] = 0u;
+    __syncthreads();
+    for (unsigned i = threadIdx.x; i < n; i += 256u) atomicAdd(&count[wf_octant(src[i].ray.d)], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned run = 0;
+        for (unsigned o = 0; o < RT_WF_BINS; ++o) {
+            start[o] = run;
+            run += count[o];
+        }
+    }
+    __syncthreads();
+    for (unsigned i = threadIdx.x; i < n; i += 256u) {
+        const WfItem it = src[i];
+        dst[atomicAdd(&start[wf_octant(it.ray.d)], 1u)] = it;
+    }
 }
 
 }  // namespace rtk

@@ -19,7 +19,7 @@ struct Wf2 {
     Wf2Space sp{};
     void* blocks[16] = {};
     size_t batch_pixels = 0, q_items = 0, node_items = 0;
-    int trace_blocks_per_cu[2][3] = {};  // [stats][mode], from the occupancy query
+    int trace_blocks_per_cu[2][4] = {};  // [stats][mode], from the occupancy query
     int n_cus = 0;
 };
 
@@ -142,6 +142,29 @@ struct Builder {
     }
 };
 
+// A copy of the subtree `id` holding only leaves for which `keep` says yes (boxes re-fitted); -1 when nothing is left.
+template <class F>
+int filtered(std::vector<TNode>& tree, uint32_t id, F&& keep) {
+    if (tree[id].shape >= 0) return keep(tree[id].shape) ? (int)id : -1;
+    TNode t;
+    for (int a = 0; a < 3; ++a) t.lo[a] = INFINITY, t.hi[a] = -INFINITY;
+    t.shape = -1;
+    const std::vector<uint32_t> kids = tree[id].kids;
+    for (uint32_t k : kids) {
+        const int f = filtered(tree, k, keep);
+        if (f < 0) continue;
+        t.kids.push_back((uint32_t)f);
+        for (int a = 0; a < 3; ++a) {
+            t.lo[a] = std::fmin(t.lo[a], tree[(size_t)f].lo[a]);
+            t.hi[a] = std::fmax(t.hi[a], tree[(size_t)f].hi[a]);
+        }
+    }
+    if (t.kids.empty()) return -1;
+    if (t.kids.size() == 1) return (int)t.kids[0];
+    tree.push_back(t);
+    return (int)tree.size() - 1;
+}
+
 template <class K>
 int occupancy(K kernel, int* out) {
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(out, kernel, 64, 0));
@@ -186,6 +209,34 @@ Plan plan_for(size_t items, size_t q_items, size_t node_items, uint32_t n_lights
     p.bytes = 2 * p.qd_cap * sizeof(WfItem) + p.node_cap * RT_WF_SHARDS * sizeof(WfNode) + p.ctx_cap * sizeof(Wf2Hit) +
               p.ctx_cap * (CX_DOUBLES * sizeof(double) + CU_UINTS * sizeof(uint32_t) + 2 * sizeof(uint32_t) + n_lights);
     return p;
+}
+
+// The workspace of a plan laid out in one block of device memory (256-byte aligned pieces); false when it does not fit.
+bool carve_space(Wf2Space& s, unsigned char* base, size_t bytes, const Plan& p, uint32_t n_lights) {
+    size_t at = 0;
+    bool ok = true;
+    auto take = [&](auto** ptr, size_t n) {
+        at = (at + 255u) & ~(size_t)255u;
+        if (at + n > bytes) ok = false;
+        *ptr = reinterpret_cast<std::remove_reference_t<decltype(**ptr)>*>(base + at);
+        at += n;
+    };
+    std::memset(&s, 0, sizeof s);
+    take(&s.ws.queue[0], p.qd_cap * sizeof(WfItem));
+    s.ws.queue[1] = s.ws.queue[0];
+    take(&s.ws.nodes, p.node_cap * RT_WF_SHARDS * sizeof(WfNode));
+    take(&s.ws.shards, RT_WF_SHARDS * sizeof(WfShard));
+    take(&s.qd, p.qd_cap * sizeof(WfItem));
+    take(&s.hits, p.ctx_cap * sizeof(Wf2Hit));
+    take(&s.ctx_d, p.ctx_cap * CX_DOUBLES * sizeof(double));
+    take(&s.ctx_u, p.ctx_cap * CU_UINTS * sizeof(uint32_t));
+    take(&s.occ, p.ctx_cap * (n_lights ? n_lights : 1u));
+    take(&s.creq, p.ctx_cap * sizeof(uint32_t));
+    take(&s.overflow, p.ctx_cap * sizeof(uint32_t));
+    take(&s.cnt, sizeof(Wf2Counters));
+    s.ws.q_cap = (unsigned)p.q_cap, s.ws.node_cap = (unsigned)p.node_cap;
+    s.qd_cap = (unsigned)p.qd_cap, s.ctx_cap = (unsigned)p.ctx_cap;
+    return ok;
 }
 
 void free_space(Wf2* w) {
@@ -266,6 +317,33 @@ int rth::wf2_create(const RtSceneDesc& d, uint32_t scene_flags, Wf2** out) {
         w->accel.root = b.emit(top, need);
         w->stack_need = need + 1u;  // + the sentinel
     }
+    {  // the hierarchy over the open primitives (see WF2_CONTAINERS in rt_wf2.h)
+        auto open = [&](int32_t shape) {
+            const RtShape& sh = d.shapes[shape];
+            const unsigned kind = RT_KIND(sh.kind_flags);
+            if (kind == RT_SPHERE || kind == RT_CUBE) return false;
+            if (kind == RT_CYLINDER || kind == RT_CONE) {
+                const RtConic& c = d.conics[sh.param];
+                return !((sh.kind_flags & RT_FLAG_CLOSED) && std::isfinite(c.minimum) && std::isfinite(c.maximum));
+            }
+            return true;
+        };
+        std::vector<uint32_t> open_top;
+        for (uint32_t id : top) {
+            const int f = filtered(tree, id, open);
+            if (f >= 0) open_top.push_back((uint32_t)f);
+        }
+        while (open_top.size() == 1 && tree[open_top[0]].shape < 0) open_top = tree[open_top[0]].kids;
+        if (open_top.empty()) {
+            w->accel.root_open = RT_BVH4_DONE;
+        } else if (open_top.size() == 1) {
+            w->accel.root_open = RT_BVH4_LEAF | (uint32_t)tree[open_top[0]].shape;
+        } else {
+            uint32_t need = 0;
+            w->accel.root_open = b.emit(open_top, need);
+            w->stack_need = std::max(w->stack_need, need + 1u);
+        }
+    }
     if (w->stack_need > RT_WF2_MAX_STACK) {
         delete w;
         return RT_OK;
@@ -277,6 +355,13 @@ int rth::wf2_create(const RtSceneDesc& d, uint32_t scene_flags, Wf2** out) {
             if (std::isfinite(t.hi[a])) w->accel.extent[a] = std::fmax(w->accel.extent[a], std::fabs(t.hi[a]));
         }
     w->accel.has_cands = d.dir_res != 0 && d.n_dir_cands != 0 ? 1u : 0u;
+    auto env_or = [](const char* name, unsigned dflt, unsigned lo, unsigned hi) {
+        const char* e = std::getenv(name);
+        const long v = e && *e ? std::atol(e) : 0;
+        return v >= (long)lo && v <= (long)hi ? (unsigned)v : dflt;
+    };
+    w->accel.chunk = env_or("RT_HIP_WF2_CHUNK", RT_WF2_CHUNK, 1u, 1u << 20);
+    w->accel.refill = env_or("RT_HIP_WF2_REFILL", RT_WF2_REFILL, 1u, 64u);
     w->n_nodes = (uint32_t)b.nodes.size();
     auto body = [&]() -> int {
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->d_nodes), (b.nodes.size() + 1) * sizeof(Bvh4Node)));
@@ -292,6 +377,7 @@ int rth::wf2_create(const RtSceneDesc& d, uint32_t scene_flags, Wf2** out) {
 #define RT_OCC(ST, MODE) if (rc == RT_OK) rc = occupancy(wf2_trace_kernel<ST, MODE>, &w->trace_blocks_per_cu[ST ? 1 : 0][MODE]);
         RT_OCC(false, WF2_PRIMARY) RT_OCC(false, WF2_QUEUE) RT_OCC(false, WF2_SHADOW)
         RT_OCC(true, WF2_PRIMARY) RT_OCC(true, WF2_QUEUE) RT_OCC(true, WF2_SHADOW)
+        RT_OCC(false, WF2_CONTAINERS) RT_OCC(true, WF2_CONTAINERS)
 #undef RT_OCC
         return rc;
     };
@@ -311,32 +397,23 @@ void rth::wf2_destroy(Wf2* w) {
     delete w;
 }
 
-int rth::wf2_render(const RtScene* scene, const RtCameraDesc* cam, uint32_t depth, const RowMap& rows_in, double* d_out,
-                    hipStream_t stream, RtStats* d_stats) {
-    Wf2* w = scene->wf2;
-    const uint32_t n_lights = scene->dev.n_lights;
-    // rows per batch: whole 8-row tiles, as many as the workspace budget holds
-    const size_t tiles_x = (cam->hsize + 7u) / 8u;
-    const size_t row_items = tiles_x * 64u / 8u;  // items per row of pixels (tiles are 8 rows high)
-    size_t batch_rows = (rows_in.n_local_rows + 7u) / 8u * 8u;
-    if (!scene->wf_q_items && !scene->wf_node_items) {
-        while (batch_rows > 8 && plan_for(batch_rows * row_items, 0, 0, n_lights).bytes > budget_bytes()) {
-            const size_t n_batches = (rows_in.n_local_rows + batch_rows - 1) / batch_rows + 1;
-            batch_rows = ((rows_in.n_local_rows + n_batches - 1) / n_batches + 7u) / 8u * 8u;
-        }
-    }
-    if (batch_rows * row_items >= 0x40000000ull) return RT_ERR_INVALID_ARG;
-    const int rc = ensure_space(w, batch_rows * row_items, scene->wf_q_items, scene->wf_node_items, n_lights);
-    if (rc != RT_OK) return rc;
-    const Wf2Space sp = w->sp;
+namespace {
+
+// The launch sequence of one frame (or row-band shard) with the workspace `sp`, `batch_rows` rows at a time.
+int run_pipeline(const RtScene* scene, const Wf2* w, const Wf2Space& sp, size_t batch_rows, const RtCameraDesc* cam, uint32_t depth,
+                 const RowMap& rows_in, double* d_out, hipStream_t stream, RtStats* d_stats) {
     const SceneDev& S = scene->dev;
     const Wf2Accel A = w->accel;
     unsigned* status = scene->d_status;
     const dim3 wide(2048), threads(256);
     auto go = [&](auto stats_tag) {
         constexpr bool ST = decltype(stats_tag)::value;
-        const dim3 tgrid[3] = {dim3((unsigned)(w->n_cus * w->trace_blocks_per_cu[ST][0])), dim3((unsigned)(w->n_cus * w->trace_blocks_per_cu[ST][1])),
-                               dim3((unsigned)(w->n_cus * w->trace_blocks_per_cu[ST][2]))};
+        const dim3 tgrid[4] = {dim3((unsigned)(w->n_cus * w->trace_blocks_per_cu[ST][0])), dim3((unsigned)(w->n_cus * w->trace_blocks_per_cu[ST][1])),
+                               dim3((unsigned)(w->n_cus * w->trace_blocks_per_cu[ST][2])), dim3((unsigned)(w->n_cus * w->trace_blocks_per_cu[ST][3]))};
+        // children of a stretch of 2^shift consecutive hits share a shard: large enough to keep neighbours together, small
+        // enough that every shard gets many stretches
+        unsigned stretch_shift = 6;
+        while (stretch_shift < RT_WF_CHUNK_SHIFT && ((size_t)sp.ctx_cap >> (stretch_shift + 1)) >= 8u * RT_WF_SHARDS) ++stretch_shift;
         for (uint32_t row0 = 0; row0 < rows_in.n_local_rows; row0 += (uint32_t)batch_rows) {
             RowMap rows = rows_in;
             rows.row0 = row0;
@@ -355,20 +432,14 @@ int rth::wf2_render(const RtScene* scene, const RtCameraDesc* cam, uint32_t dept
                 }
                 if (A.has_cands) hipLaunchKernelGGL((wf2_cands_kernel<ST, WF2_SHADOW>), wide, threads, 0, stream, S, sp, *cam, rows, g, d_stats, status);
                 hipLaunchKernelGGL((wf2_trace_kernel<ST, WF2_SHADOW>), tgrid[2], dim3(64), 0, stream, S, A, sp, *cam, rows, g, d_stats, status);
-                if (g < depth && (S.flags & RT_SCENE_RECURSIVE)) {  // only hits with recursion budget left ask for n1 / n2
-                    if (g == 0)
-                        hipLaunchKernelGGL((wf2_containers_kernel<ST, true>), dim3(4096), dim3(64), 0, stream, S, sp, *cam, rows, d_stats, status);
-                    else
-                        hipLaunchKernelGGL((wf2_containers_kernel<ST, false>), dim3(4096), dim3(64), 0, stream, S, sp, *cam, rows, d_stats, status);
-                }
-                hipLaunchKernelGGL((wf2_finish_kernel<ST>), wide, threads, 0, stream, S, sp, g, d_out, d_stats, status);
-                if (g < depth && (S.flags & RT_SCENE_RECURSIVE)) {
-                    hipLaunchKernelGGL((wf2_overflow_kernel<ST>), dim3(4096), dim3(64), 0, stream, S, sp, d_out, d_stats, status);
-                    hipLaunchKernelGGL(wf2_scan_kernel, dim3(1), dim3(RT_WF_SHARDS), 0, stream, sp, g);
-                    hipLaunchKernelGGL(wf2_compact_kernel, dim3(RT_WF_SHARDS * RT_WF_BINS * 2u), threads, 0, stream, sp, g);
-                } else {
-                    break;  // nothing can have been queued
-                }
+                const bool more = g < depth && (S.flags & RT_SCENE_RECURSIVE);  // only hits with recursion budget left can have children
+                if (more)
+                    hipLaunchKernelGGL((wf2_trace_kernel<ST, WF2_CONTAINERS>), tgrid[3], dim3(64), 0, stream, S, A, sp, *cam, rows, g, d_stats, status);
+                hipLaunchKernelGGL((wf2_finish_kernel<ST>), wide, threads, 0, stream, S, sp, g, stretch_shift, d_out, d_stats, status);
+                if (!more) break;
+                hipLaunchKernelGGL((wf2_overflow_kernel<ST>), dim3(4096), dim3(64), 0, stream, S, sp, d_out, d_stats, status);
+                hipLaunchKernelGGL(wf2_scan_kernel, dim3(1), dim3(RT_WF_SHARDS), 0, stream, sp, g);
+                hipLaunchKernelGGL(wf2_compact_kernel, dim3(RT_WF_SHARDS), threads, 0, stream, sp, g);
             }
             if (S.flags & RT_SCENE_RECURSIVE)
                 for (unsigned k = depth; k-- > 0;) rth::launch_combine(sp.ws, k, d_out, stream);
@@ -382,7 +453,31 @@ int rth::wf2_render(const RtScene* scene, const RtCameraDesc* cam, uint32_t dept
     return RT_OK;
 }
 
+// items per row of pixels: tiles are 8 x 8 pixels, 64 items
+size_t items_per_row(const RtCameraDesc* cam) { return (size_t)((cam->hsize + 7u) / 8u) * 8u; }
+
+}  // namespace
+
+int rth::wf2_render(const RtScene* scene, const RtCameraDesc* cam, uint32_t depth, const RowMap& rows_in, double* d_out,
+                    hipStream_t stream, RtStats* d_stats) {
+    Wf2* w = scene->wf2;
+    const uint32_t n_lights = scene->dev.n_lights;
+    // rows per batch: whole 8-row tiles, as many as the workspace budget holds
+    const size_t row_items = items_per_row(cam);
+    size_t batch_rows = (rows_in.n_local_rows + 7u) / 8u * 8u;
+    if (!scene->wf_q_items && !scene->wf_node_items) {
+        while (batch_rows > 8 && plan_for(batch_rows * row_items, 0, 0, n_lights).bytes > budget_bytes()) {
+            const size_t n_batches = (rows_in.n_local_rows + batch_rows - 1) / batch_rows + 1;
+            batch_rows = ((rows_in.n_local_rows + n_batches - 1) / n_batches + 7u) / 8u * 8u;
+        }
+    }
+    if (batch_rows * row_items >= 0x40000000ull) return RT_ERR_INVALID_ARG;
+    const int rc = ensure_space(w, batch_rows * row_items, scene->wf_q_items, scene->wf_node_items, n_lights);
+    if (rc != RT_OK) return rc;
+    return run_pipeline(scene, w, w->sp, batch_rows, cam, depth, rows_in, d_out, stream, d_stats);
+}
+
 const char* rth::wf2_describe() {
     return "kernel pipeline per generation of rays: wf2_trace_kernel (4-wide f32 hierarchy, persistent waves) for colour rays and "
-           "shadow feelers + wf2_cands / wf2_prepare / wf2_containers / wf2_finish / wf2_overflow / wf2_compact + wf_combine_kernel";
+           "shadow feelers + wf2_cands / wf2_prepare / wf2_finish / wf2_overflow / wf2_compact + wf_combine_kernel";
 }
