@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_DIR = os.path.join(_HERE, "lib")
+# RT_HIP_LIB_DIR: another build of the two libraries (kernel variants compiled with other -D settings, for studies)
+LIB_DIR = os.environ.get("RT_HIP_LIB_DIR") or os.path.join(_HERE, "lib")
 REPO_ROOT = os.path.dirname(_HERE)
 
 

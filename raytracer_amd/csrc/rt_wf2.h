@@ -15,13 +15,15 @@
 //   wf2_prepare_kernel   prepare_computations + the pattern colour (intersection.rs:45-99, pattern.rs:76-91) of
 //                        every hit; hits are compacted into shading contexts, one shadow feeler per light each
 //                        A third mode builds the sorted list of the world's intersections up to a transparent hit and
-//                        walks it for n1 / n2 (intersection.rs:50-75).  The reference lists what the whole line meets,
-//                        behind the origin too; an entry pair of a CLOSED primitive (sphere, cube, capped conic) that
-//                        lies wholly before the hit pushes and removes that primitive again and leaves no trace in
-//                        `containers`, so closed primitives are looked for only along the segment from the origin
-//                        to the hit (a closed primitive around the origin has the origin in its box) and only the
-//                        open ones (planes, triangles, uncapped conics), which a line can cross an odd number of
-//                        times, along the whole line -- through a second, small hierarchy over them.
+//                        walks it for n1 / n2 (intersection.rs:50-75).  The reference lists what the whole LINE meets,
+//                        behind the origin too, and so does this walk.  (Measured and not adopted: closed primitives
+//                        -- sphere, cube, capped conic -- looked for only along the segment from the origin to the
+//                        hit and only the open ones along the whole line, on the grounds that an entry PAIR wholly
+//                        before the hit pushes and removes its primitive and leaves no trace in `containers`.  A third
+//                        of the walk's time, 7.9 -> 2.6 ms per 4K frame of the 10k scene -- but a ray that clips the
+//                        edge of a cube behind the origin with a chord under 1e-5 has its two entries merged into
+//                        ONE by the set's dedupe (primitive.rs:227-230), an odd count that the reference keeps in
+//                        `containers`: one pixel of 1.1 M differed at 7680x4320.  RT_HIP_WF2_SEG_NEAR=1 runs it.)
 //   wf2_finish_kernel    lighting per light (primitive.rs:111-151), reflected / refracted children
 //                        (world.rs:98-127, schlick intersection.rs:182-200) into the next generation's queue
 //   wf2_overflow_kernel  hits whose children found no room keep their subtree (color_at's frame stack)
@@ -53,6 +55,8 @@ struct Wf2Accel {
     uint32_t has_cands;  // the scene has a direction index
     uint32_t chunk;      // rays a wave takes from the queue at a time
     uint32_t refill;     // idle lanes that make a wave go back to the queue
+    float slack;         // slack of the f32 box test, as a fraction of |o| + extent (2^-20; RT_HIP_WF2_SLACK scales it: studies)
+    float seg_near;      // containers walk: how far behind the origin the segment walk starts (RT_HIP_WF2_SEG_NEAR: studies)
 };
 
 struct Wf2Hit {  // closest hit of one colour ray
@@ -170,7 +174,7 @@ struct RayF32 {
 };
 RT_DEV float f32_up(double x) { return __double2float_ru(x); }
 RT_DEV float f32_down(double x) { return __double2float_rd(x); }
-RT_DEV void ray_f32(const Ray& r, const float extent[3], RayF32& f) {
+RT_DEV void ray_f32(const Ray& r, const float extent[3], float slack, RayF32& f) {
     const double o[3] = {r.o.x, r.o.y, r.o.z}, d[3] = {r.d.x, r.d.y, r.d.z};
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -179,7 +183,7 @@ RT_DEV void ray_f32(const Ray& r, const float extent[3], RayF32& f) {
         if (!(fabs(inv) <= 1e18)) inv = (d[a] < 0.0 || (d[a] == 0.0 && __double_as_longlong(d[a]) < 0)) ? -1e18 : 1e18;
         const float invf = (float)inv;
         const double c = -o[a] * (double)invf;
-        const double k = fabs((double)invf) * (1.0 / 1048576.0) * (fabs(o[a]) + (double)extent[a]);
+        const double k = fabs((double)invf) * (double)slack * (fabs(o[a]) + (double)extent[a]);
         f.inv[a] = invf;
         // the plane met first is lo when the slope is positive, hi when it is negative; first planes move down, second up
         f.cl[a] = invf >= 0.f ? f32_down(c - k) : f32_up(c + k);
@@ -500,12 +504,13 @@ __global__ __launch_bounds__(64, RT_WF2_TRACE_WAVES) void wf2_trace_kernel(const
                             }
                         }
                     }
-                    ray_f32(ray, A.extent, f);
+                    ray_f32(ray, A.extent, A.slack, f);
                     t_far = (SHADOW || LIST) ? f32_up(limit) : f32_up(best.t);
-                    // LIST: what the containers walk can read of the list (see below) is found by two walks: everything that
-                    // meets the segment from just behind the origin to the cut, then the open primitives along the whole line
-                    t_near = LIST ? -1e-2f : 0.f;
-                    second_walk = LIST;
+                    // LIST: the list is what the whole LINE meets up to the cut, behind the origin too (seg_near = -inf).
+                    // (Study, RT_HIP_WF2_SEG_NEAR=1: a finite seg_near and a second walk over the open primitives only; see
+                    // the header of this file for why that is not the default.)
+                    t_near = LIST ? A.seg_near : 0.f;
+                    second_walk = LIST && A.seg_near > -__builtin_inff();
                     lds_stack[0] = RT_BVH4_DONE;
                     w.sp = 1;
                     w.cur = (valid && !found) ? A.root : RT_BVH4_DONE;

@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include "rt_host_internal.h"
 #include "rt_wf2.h"
@@ -362,6 +363,8 @@ int rth::wf2_create(const RtSceneDesc& d, uint32_t scene_flags, Wf2** out) {
     };
     w->accel.chunk = env_or("RT_HIP_WF2_CHUNK", RT_WF2_CHUNK, 1u, 1u << 20);
     w->accel.refill = env_or("RT_HIP_WF2_REFILL", RT_WF2_REFILL, 1u, 64u);
+    w->accel.slack = (1.0f / 1048576.0f) * (float)env_or("RT_HIP_WF2_SLACK", 1u, 1u, 1u << 20);
+    w->accel.seg_near = env_or("RT_HIP_WF2_SEG_NEAR", 0u, 0u, 1u) ? -1e-2f : -INFINITY;
     w->n_nodes = (uint32_t)b.nodes.size();
     auto body = [&]() -> int {
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->d_nodes), (b.nodes.size() + 1) * sizeof(Bvh4Node)));
