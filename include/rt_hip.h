@@ -45,7 +45,8 @@ enum {
     RT_ERR_NAN_T = -7,         /* run time: a NaN intersection distance was dropped
                                   (the reference would panic: intersection.rs:119)   */
     RT_ERR_INVALID_ARG = -8,
-    RT_ERR_DEPTH = -9          /* recursion budget above RT_MAX_DEPTH                */
+    RT_ERR_DEPTH = -9,         /* recursion budget above RT_MAX_DEPTH                */
+    RT_ERR_NOALLOC_SIZE = -10  /* rt_hip_render_rows_noalloc: the frame is too wide for the fixed workspace */
 };
 
 #define RT_MAX_NEST 8    /* max compound (group/CSG) nesting above a primitive      */
@@ -294,6 +295,21 @@ int rt_hip_scene_render_rgb8(const RtScene* scene, const RtCameraDesc* cam, uint
 int rt_hip_render_rows(const RtScene* scene, const RtCameraDesc* cam, uint32_t depth, uint32_t part,
                        uint32_t n_parts, uint32_t band_rows, uint32_t n_local_rows,
                        double* d_out_rgb, void* hip_stream, RtStats* d_stats);
+
+/* rt_hip_render_rows for callers that cannot allocate device memory -- code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc.  It has NO counterpart in the reference.  Same arguments,
+ * same frame bit for bit, but no hipMalloc / hipFree and no other allocating call on any path: where
+ * rt_hip_render_rows would use the wave-front workspace (large scenes, mode 2 of rt_hip_scene_set_wavefront)
+ * the kernels work in a fixed 128 MiB array in device memory that belongs to the library (one copy per GPU
+ * the library runs on, held until the process ends), rendering the rows in batches that fit it; every other
+ * scene is rendered by the one-launch kernel (mode 0), which needs no workspace.
+ * Limit: one batch is at least 8 rows, so hsize can be at most about 30 000 pixels; wider frames are refused
+ * with RT_ERR_NOALLOC_SIZE.  Every call on one GPU shares that GPU's array (each call clears the counters it
+ * needs at zero): calls that overlap in time on one GPU -- other streams, other threads, other scenes --
+ * race; order them.  rt_hip_scene_set_wavefront's capacities do not apply. */
+int rt_hip_render_rows_noalloc(const RtScene* scene, const RtCameraDesc* cam, uint32_t depth, uint32_t part,
+                               uint32_t n_parts, uint32_t band_rows, uint32_t n_local_rows,
+                               double* d_out_rgb, void* hip_stream, RtStats* d_stats);
 
 /* How launches on this scene organise color_at's recursion (world.rs:98-127); the image is the same
  * either way, bit for bit.  mode 0: one launch, every lane keeps the whole ray tree of its pixel.

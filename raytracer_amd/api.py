@@ -425,6 +425,12 @@ class DeviceScene:
                                          C.c_void_p(d_out_ptr), C.c_void_p(stream or 0), C.c_void_p(d_stats_ptr or 0)),
                 "rt_hip_render_rows")
 
+    def render_rows_noalloc(self, cam_desc, depth, part, n_parts, band_rows, n_local_rows, d_out_ptr, stream=None, d_stats_ptr=None):
+        """rt_hip_render_rows_noalloc: the same call with no device allocation on any path."""
+        N.check(N.hip.rt_hip_render_rows_noalloc(self._p, C.byref(cam_desc), depth, part, n_parts, band_rows, n_local_rows,
+                                                 C.c_void_p(d_out_ptr), C.c_void_p(stream or 0), C.c_void_p(d_stats_ptr or 0)),
+                "rt_hip_render_rows_noalloc")
+
     def render(self, camera, stats=False):
         """`camera.render(&world)` on the resident scene (rt_hip_scene_render): Canvas of f64 colours."""
         out = np.empty((camera.v_size, camera.h_size, 3), dtype=np.float64)

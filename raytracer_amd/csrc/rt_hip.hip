@@ -455,8 +455,10 @@ int ensure_wavefront_space(const RtScene* scene, size_t pixels) {
     return RT_OK;
 }
 
+// no_alloc: rt_hip_render_rows_noalloc -- the pipeline works in the library's fixed array, the older generation kernels
+// (whose workspace is allocated) are not used
 int launch_render(const RtScene* scene, const RtCameraDesc* cam, uint32_t depth, const RowMap& rows, double* d_out,
-                  hipStream_t stream, RtStats* d_stats) {
+                  hipStream_t stream, RtStats* d_stats, bool no_alloc = false) {
     const dim3 block(256);
     const dim3 grid((cam->hsize + 15u) / 16u, (rows.n_local_rows + 15u) / 16u);
     if (grid.y > 65535u * 16u) return RT_ERR_INVALID_ARG;
@@ -486,11 +488,12 @@ int launch_render(const RtScene* scene, const RtCameraDesc* cam, uint32_t depth,
     // waves over a 4-wide hierarchy, shading in between.  If its workspace cannot be had the one-launch kernel below
     // renders the same frame.
     if (scene->wf2 && pixels < 0x20000000ull && (mode == 2 || (mode < 0 && large && can_wavefront))) {
+        if (no_alloc) return rth::wf2_render_noalloc(scene, cam, depth, rows, d_out, stream, d_stats);
         const int rc = rth::wf2_render(scene, cam, depth, rows, d_out, stream, d_stats);
         if (rc != RT_ERR_HIP) return rc;
         (void)hipGetLastError();
     }
-    bool wavefront = can_wavefront && (mode >= 1 || (mode < 0 && large));
+    bool wavefront = !no_alloc && can_wavefront && (mode >= 1 || (mode < 0 && large));
     if (wavefront && ensure_wavefront_space(scene, pixels) != RT_OK) {  // no room for queues and nodes: same frame, one launch
         (void)hipGetLastError();
         wavefront = false;
@@ -592,7 +595,7 @@ int rt_hip_init(int device) {
     HIP_TRY(hipSetDevice(device));
     g_device = device;
     g_initialised = true;
-    return RT_OK;
+    return rth::scratch_init();  // the address of this device's copy of the fixed workspace (rt_hip_render_rows_noalloc)
 }
 
 void rt_hip_shutdown(void) {
@@ -618,6 +621,7 @@ const char* rt_hip_strerror(int code) {
         case RT_ERR_NAN_T: return "a NaN intersection distance was dropped (the reference panics: t is not NaN)";
         case RT_ERR_INVALID_ARG: return "invalid argument";
         case RT_ERR_DEPTH: return "recursion budget above RT_MAX_DEPTH";
+        case RT_ERR_NOALLOC_SIZE: return "rt_hip_render_rows_noalloc: the frame is too wide for the library's fixed 128 MiB workspace (8 rows must fit)";
         default: return "unknown error";
     }
 }
@@ -811,7 +815,18 @@ int rt_hip_render_rows(const RtScene* scene, const RtCameraDesc* cam, uint32_t d
     return launch_render(scene, cam, depth, rows, d_out_rgb, static_cast<hipStream_t>(hip_stream), d_stats);
 }
 
-// Camera::render with the frame returned as f64 colours (out_rgb) or as the 8-bit samples Canvas::to_ppm prints (out_rgb8)
+int rt_hip_render_rows_noalloc(const RtScene* scene, const RtCameraDesc* cam, uint32_t depth, uint32_t part, uint32_t n_parts,
+                               uint32_t band_rows, uint32_t n_local_rows, double* d_out_rgb, void* hip_stream,
+                               RtStats* d_stats) {
+    if (!scene || !d_out_rgb || n_parts == 0 || part >= n_parts || band_rows == 0) return RT_ERR_INVALID_ARG;
+    RT_ON_DEVICE_OF(scene);
+    const int rc = check_camera(cam, depth);
+    if (rc != RT_OK) return rc;
+    if (n_local_rows == 0) return RT_OK;
+    const RowMap rows{part, n_parts, band_rows, n_local_rows};
+    return launch_render(scene, cam, depth, rows, d_out_rgb, static_cast<hipStream_t>(hip_stream), d_stats, true);
+}
+
 // Camera::render on a resident scene, the frame returned as f64 colours (out_rgb) and / or as the 8-bit
 // samples Canvas::to_ppm prints (out_rgb8).  The device framebuffers belong to the scene and are reused.
 static int scene_render_to_host(const RtScene* scene, const RtCameraDesc* cam, uint32_t depth, double* out_rgb,

@@ -46,6 +46,13 @@ void wf2_destroy(Wf2* w);
 int wf2_render(const RtScene* scene, const RtCameraDesc* cam, uint32_t depth, const rtk::RowMap& rows, double* d_out,
                hipStream_t stream, RtStats* d_stats);
 const char* wf2_describe();
+// The same frame with the workspace in the library's fixed device array (no allocation): rows are rendered in batches
+// that fit it.  RT_ERR_NOALLOC_SIZE when not even one 8-row tile of this width fits.
+#define RT_NOALLOC_SCRATCH_BYTES (128u << 20)
+int wf2_render_noalloc(const RtScene* scene, const RtCameraDesc* cam, uint32_t depth, const rtk::RowMap& rows, double* d_out,
+                       hipStream_t stream, RtStats* d_stats);
+// hipGetSymbolAddress of that array for the CURRENT device, once per device (rt_hip_init, or the first call that needs it)
+int scratch_init();
 // rt_hip.hip: shade_hit's last line for the nodes of one generation (used by both wave-front forms)
 void launch_combine(const rtd::WfSpace& ws, unsigned level, double* d_out, hipStream_t stream);
 }  // namespace rth

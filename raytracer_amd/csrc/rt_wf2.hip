@@ -480,6 +480,58 @@ int rth::wf2_render(const RtScene* scene, const RtCameraDesc* cam, uint32_t dept
     return run_pipeline(scene, w, w->sp, batch_rows, cam, depth, rows_in, d_out, stream, d_stats);
 }
 
+// ---- the entry point that allocates nothing (rt_hip_render_rows_noalloc) -------------------------------------------
+// Its workspace is this array: each GPU the library runs on holds its own copy, at its own address, until the process
+// ends.  In host code the array's NAME is only a handle for hipGetSymbolAddress; everything below uses the per-device
+// address that call returned (kernel arguments, hipMemsetAsync).
+static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_SCRATCH_BYTES];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+unsigned char* g_scratch_ptr[kMaxDevices] = {};
+}  // namespace
+
+int rth::scratch_init() {
+    int dev = -1;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices) return RT_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_ptr[dev]) return RT_OK;
+    void* ptr = nullptr;
+    HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));  // the current device's copy
+    if (!ptr) return RT_ERR_HIP;
+    g_scratch_ptr[dev] = static_cast<unsigned char*>(ptr);
+    return RT_OK;
+}
+
+int rth::wf2_render_noalloc(const RtScene* scene, const RtCameraDesc* cam, uint32_t depth, const RowMap& rows_in, double* d_out,
+                            hipStream_t stream, RtStats* d_stats) {
+    const int rc = rth::scratch_init();  // (the scene's device is current: the caller's guard)
+    if (rc != RT_OK) return rc;
+    unsigned char* base = g_scratch_ptr[scene->device];
+    const uint32_t n_lights = scene->dev.n_lights;
+    const size_t row_items = items_per_row(cam);
+    // the tallest batch of whole 8-row tiles whose workspace fits the array
+    Wf2Space sp;
+    size_t lo = 0, hi = (rows_in.n_local_rows + 7u) / 8u;  // in tiles of 8 rows: lo fits (0 = nothing yet), hi + 1 does not
+    auto fits = [&](size_t tiles) {
+        const size_t items = tiles * 8u * row_items;
+        if (items >= 0x40000000ull) return false;
+        Wf2Space probe;
+        return carve_space(probe, base, RT_NOALLOC_SCRATCH_BYTES, plan_for(items, 0, 0, n_lights), n_lights);
+    };
+    if (!fits(1)) return RT_ERR_NOALLOC_SIZE;
+    lo = 1;
+    while (lo < hi) {
+        const size_t mid = (lo + hi + 1) / 2;
+        if (fits(mid)) lo = mid; else hi = mid - 1;
+    }
+    const size_t batch_rows = lo * 8u;
+    (void)carve_space(sp, base, RT_NOALLOC_SCRATCH_BYTES, plan_for(batch_rows * row_items, 0, 0, n_lights), n_lights);
+    return run_pipeline(scene, scene->wf2, sp, batch_rows, cam, depth, rows_in, d_out, stream, d_stats);
+}
+
 const char* rth::wf2_describe() {
     return "kernel pipeline per generation of rays: wf2_trace_kernel (4-wide f32 hierarchy, persistent waves) for colour rays and "
            "shadow feelers + wf2_cands / wf2_prepare / wf2_finish / wf2_overflow / wf2_compact + wf_combine_kernel";
