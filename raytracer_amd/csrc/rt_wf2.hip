@@ -2,6 +2,7 @@
 // scene's skip-link nodes, the workspace, and the launch sequence of one frame.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -13,6 +14,7 @@ using namespace rtd;
 using namespace rtk;
 
 struct Wf2 {
+    LeafPre* d_pre = nullptr;
     Bvh4Node* d_nodes = nullptr;
     Wf2Accel accel{};
     uint32_t n_nodes = 0, stack_need = 0;
@@ -68,6 +70,7 @@ struct Builder {
     std::vector<TNode>& tree;
     std::vector<Bvh4Node> nodes;
     uint32_t stack_need = 0;
+    bool ok = true;  // false: some box cannot be put on a node's 8-bit grid (not finite): the scene keeps the older kernels
 
     // at most four subtrees out of `list`: inner ones are opened up (largest first) while the result still fits four;
     // longer lists are cut into four runs, each under a synthetic inner node
@@ -122,13 +125,34 @@ struct Builder {
         Bvh4Node nd;
         std::memset(&nd, 0, sizeof nd);
         uint32_t deepest = 0;
-        for (int c = 0; c < 4; ++c) {
-            for (int a = 0; a < 3; ++a) nd.lo[a][c] = INFINITY, nd.hi[a][c] = -INFINITY;
-            nd.child[c] = (int32_t)RT_BVH4_DONE;
+        // the grid: origin = the children's common lower corner, step = the power of two that brings the common upper
+        // corner within 255 steps
+        double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (uint32_t id : list)
+            for (int a = 0; a < 3; ++a) {
+                if (!std::isfinite(tree[id].lo[a]) || !std::isfinite(tree[id].hi[a]) || tree[id].lo[a] > tree[id].hi[a]) ok = false;
+                lo[a] = std::fmin(lo[a], tree[id].lo[a]), hi[a] = std::fmax(hi[a], tree[id].hi[a]);
+            }
+        double step[3];
+        for (int a = 0; a < 3; ++a) {
+            nd.org[a] = (float)lo[a];  // exact: the corner is one of the f32 box values
+            int e = 0;
+            std::frexp(std::fmax((hi[a] - lo[a]) / 255.0, 1e-37), &e);  // (hi - lo) / 255 <= 2^e
+            int biased = e + 127;
+            if (biased < 1) biased = 1;
+            if (biased > 254) ok = false, biased = 254;
+            nd.exp[a] = (uint8_t)biased;
+            step[a] = std::ldexp(1.0, biased - 127);
         }
+        for (int c = 0; c < 4; ++c) nd.child[c] = (int32_t)RT_BVH4_DONE;
         for (size_t c = 0; c < list.size(); ++c) {
             const TNode t = tree[list[c]];
-            for (int a = 0; a < 3; ++a) nd.lo[a][c] = t.lo[a], nd.hi[a][c] = t.hi[a];
+            for (int a = 0; a < 3; ++a) {
+                const double ql = std::floor(((double)t.lo[a] - lo[a]) / step[a]), qh = std::ceil(((double)t.hi[a] - lo[a]) / step[a]);
+                if (!(ql >= 0.0 && qh <= 255.0 && ql <= qh)) ok = false;
+                nd.qlo[a][c] = (uint8_t)std::fmax(0.0, std::fmin(255.0, ql));
+                nd.qhi[a][c] = (uint8_t)std::fmax(0.0, std::fmin(255.0, qh));
+            }
             if (t.shape >= 0) {
                 nd.child[c] = (int32_t)(RT_BVH4_LEAF | (uint32_t)t.shape);
             } else {
@@ -164,6 +188,84 @@ int filtered(std::vector<TNode>& tree, uint32_t id, F&& keep) {
     if (t.kids.size() == 1) return (int)t.kids[0];
     tree.push_back(t);
     return (int)tree.size() - 1;
+}
+
+// ---- the f32 test ahead of a leaf (LeafPre) ---------------------------------------------------------------------
+// C = inverse(primitive) * inverse(parent) * ... * inverse(outermost group) in f64 (what the reference applies one matrix
+// at a time), rounded to f32, with the constants that bound what the f32 evaluation can be off by in OBJECT space:
+//   position: every term of C32 * o32 + c32 and of the shift along the line rounds by <= 2^-23 of its size, and the sizes
+//             add up to at most (sum_j |C_ij| + |c_i| / E) * (max |o| + E) with E = the scene's extent: k1 = 2^-17 of that
+//             row norm (16 roundings' worth);
+//   direction: |du| <= 2^-22 |C| |d|, which moves the line by at most rho * |du| / |u| <= rho * 2^-22 * cond(C) * sqrt(3) over
+//             the rho = the shape's bounding radius that matters: into k2, with a base of 1e-3 that also covers the f64
+//             side's own rounding for origins up to ~1e5 object sizes away (cf. ABox::pad in the flattener).
+// Shapes whose bound is not small and finite in object space, or whose constants come out large, get no test.
+LeafPre leaf_pre_of(const RtSceneDesc& d, uint32_t shape, double extent) {
+    LeafPre out;
+    std::memset(&out, 0, sizeof out);
+    out.kind = RT_PRE_NONE;
+    const RtShape& sh = d.shapes[shape];
+    const unsigned kind = RT_KIND(sh.kind_flags);
+    double rho = 1.7320508075688772;  // cube; sphere 1
+    double ymid = 0.0, yhalf = 1.0, radius = 1.0;
+    if (kind == RT_CYLINDER || kind == RT_CONE) {
+        const RtConic& c = d.conics[sh.param];
+        if (!(c.minimum <= c.maximum)) return out;
+        const bool finite = std::isfinite(c.minimum) && std::isfinite(c.maximum);
+        if (kind == RT_CONE && !finite) return out;  // its radius grows with |y|
+        radius = kind == RT_CONE ? std::fmax(std::fabs(c.minimum), std::fabs(c.maximum)) : 1.0;
+        ymid = finite ? 0.5 * (c.minimum + c.maximum) : 0.0;
+        yhalf = finite ? 0.5 * (c.maximum - c.minimum) : INFINITY;
+        rho = std::sqrt(radius * radius + (finite ? std::fmax(c.minimum * c.minimum, c.maximum * c.maximum) : 0.0));
+        if (!finite) rho = 64.0;  // (only the radial part of the test is finite; the direction term below is then void: no test)
+        if (!finite) return out;
+    } else if (kind != RT_SPHERE && kind != RT_CUBE) {
+        return out;  // planes and triangles: always the f64 test
+    }
+    if (!(rho <= 64.0)) return out;
+    // compose, innermost last: p_obj = inv_prim * (inv_parent * (... * (inv_outermost * p)))
+    double C[3][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}};
+    std::vector<int32_t> chain;
+    for (int32_t p = sh.parent; p >= 0; p = d.shapes[p].parent) chain.push_back(p);
+    auto apply = [&](const double* m) {  // C = M * C
+        double r[3][4];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 4; ++j) {
+                double v = j == 3 ? m[i * 4 + 3] : 0.0;
+                for (int k = 0; k < 3; ++k) v += m[i * 4 + k] * C[k][j];
+                r[i][j] = v;
+            }
+        std::memcpy(C, r, sizeof r);
+    };
+    for (size_t q = chain.size(); q-- > 0;) apply(d.shapes[chain[q]].inv);
+    apply(sh.inv);
+    // norms of the linear part and of its inverse
+    const double a = C[0][0], b = C[0][1], c = C[0][2], e = C[1][0], f = C[1][1], g = C[1][2], h = C[2][0], i2 = C[2][1], j2 = C[2][2];
+    const double det = a * (f * j2 - g * i2) - b * (e * j2 - g * h) + c * (e * i2 - f * h);
+    if (!(std::fabs(det) > 1e-300) || !std::isfinite(det)) return out;
+    const double inv3[3][3] = {{(f * j2 - g * i2) / det, (c * i2 - b * j2) / det, (b * g - c * f) / det},
+                               {(g * h - e * j2) / det, (a * j2 - c * h) / det, (c * e - a * g) / det},
+                               {(e * i2 - f * h) / det, (b * h - a * i2) / det, (a * f - b * e) / det}};
+    double norm = 0.0, norm_inv = 0.0, row = 0.0;
+    const double E = std::fmax(extent, 1.0);
+    for (int r = 0; r < 3; ++r) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int k = 0; k < 3; ++k) s1 += std::fabs(C[r][k]), s2 += std::fabs(inv3[r][k]);
+        norm = std::fmax(norm, s1), norm_inv = std::fmax(norm_inv, s2);
+        row = std::fmax(row, s1 + std::fabs(C[r][3]) / E);
+    }
+    const double k1 = row / 131072.0;                                                  // 2^-17
+    const double k2 = 1e-3 + rho * norm * norm_inv * 3.0 * 1.7320508075688772 / 4194304.0;  // 2^-22, infinity norms: sqrt(3) each way
+    if (!(k1 * 2.0 * E <= 0.125) || !(k2 <= 0.125) || !std::isfinite(k1) || !std::isfinite(k2)) return out;  // too loose to be worth it
+    for (int r = 0; r < 3; ++r)
+        for (int k = 0; k < 4; ++k) {
+            out.m[r * 4 + k] = (float)C[r][k];
+            if (!std::isfinite(out.m[r * 4 + k])) return out;
+        }
+    out.k1 = (float)(k1 * 1.0001), out.k2 = (float)(k2 * 1.0001);
+    out.ymid = (float)ymid, out.yhalf = (float)(yhalf * 1.0001), out.radius = (float)(radius * 1.0001);
+    out.kind = kind;
+    return out;
 }
 
 template <class K>
@@ -309,8 +411,28 @@ int rth::wf2_create(const RtSceneDesc& d, uint32_t scene_flags, Wf2** out) {
         if (t.shape >= 0 && RT_KIND(d.shapes[t.shape].kind_flags) > RT_SMOOTH_TRIANGLE) return RT_OK;
     Wf2* w = new Wf2();
     Builder b{tree, {}, 0};
+    {  // leaves with unbounded boxes (the flattener puts them after the tree) stay outside the hierarchy: every ray tests them
+        std::vector<uint32_t> bounded;
+        for (uint32_t id : top) {
+            const TNode& t = tree[id];
+            bool finite = true;
+            for (int a = 0; a < 3; ++a) finite = finite && std::isfinite(t.lo[a]) && std::isfinite(t.hi[a]);
+            if (finite) {
+                bounded.push_back(id);
+            } else if (t.shape >= 0 && w->accel.n_always < 8u) {
+                w->accel.always[w->accel.n_always++] = (uint32_t)t.shape;
+            } else {  // an unbounded inner node, or too many unbounded leaves
+                delete w;
+                return RT_OK;
+            }
+        }
+        top = bounded;
+    }
     while (top.size() == 1 && tree[top[0]].shape < 0) top = tree[top[0]].kids;
-    if (top.size() == 1) {
+    if (top.empty()) {
+        w->accel.root = RT_BVH4_DONE;
+        w->stack_need = 1;
+    } else if (top.size() == 1) {
         w->accel.root = RT_BVH4_LEAF | (uint32_t)tree[top[0]].shape;
         w->stack_need = 1;
     } else {
@@ -345,7 +467,8 @@ int rth::wf2_create(const RtSceneDesc& d, uint32_t scene_flags, Wf2** out) {
             w->stack_need = std::max(w->stack_need, need + 1u);
         }
     }
-    if (w->stack_need > RT_WF2_MAX_STACK) {
+    w->stack_need += w->accel.n_always;
+    if (w->stack_need > RT_WF2_MAX_STACK || !b.ok) {
         delete w;
         return RT_OK;
     }
@@ -356,6 +479,20 @@ int rth::wf2_create(const RtSceneDesc& d, uint32_t scene_flags, Wf2** out) {
             if (std::isfinite(t.hi[a])) w->accel.extent[a] = std::fmax(w->accel.extent[a], std::fabs(t.hi[a]));
         }
     w->accel.has_cands = d.dir_res != 0 && d.n_dir_cands != 0 ? 1u : 0u;
+    w->accel.extent_max = std::fmax(w->accel.extent[0], std::fmax(w->accel.extent[1], w->accel.extent[2]));
+    std::vector<LeafPre> pre(d.n_shapes);
+    for (LeafPre& p : pre) std::memset(&p, 0, sizeof p), p.kind = RT_PRE_NONE, p.anc[0] = RT_PRE_DEEP, p.anc[1] = RT_PRE_NO_ANC;
+    for (const TNode& t : tree)
+        if (t.shape >= 0) {
+            LeafPre& p = pre[(size_t)t.shape];
+            p = leaf_pre_of(d, (uint32_t)t.shape, w->accel.extent_max);
+            // the enclosing groups, outermost first, when there are at most two
+            std::vector<int32_t> chain;
+            for (int32_t a = d.shapes[t.shape].parent; a >= 0; a = d.shapes[a].parent) chain.push_back(a);
+            p.anc[0] = p.anc[1] = RT_PRE_NO_ANC;
+            if (chain.size() > 2) p.anc[0] = RT_PRE_DEEP;
+            else for (size_t k = 0; k < chain.size(); ++k) p.anc[k] = (uint32_t)chain[chain.size() - 1 - k];
+        }
     auto env_or = [](const char* name, unsigned dflt, unsigned lo, unsigned hi) {
         const char* e = std::getenv(name);
         const long v = e && *e ? std::atol(e) : 0;
@@ -371,6 +508,12 @@ int rth::wf2_create(const RtSceneDesc& d, uint32_t scene_flags, Wf2** out) {
         if (!b.nodes.empty())
             HIP_TRY(hipMemcpy(w->d_nodes, b.nodes.data(), b.nodes.size() * sizeof(Bvh4Node), hipMemcpyHostToDevice));
         w->accel.nodes = w->d_nodes;
+        const char* pre_env = std::getenv("RT_HIP_WF2_PRE");
+        if (!(pre_env && *pre_env == '0')) {
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->d_pre), (pre.size() + 1) * sizeof(LeafPre)));
+            HIP_TRY(hipMemcpy(w->d_pre, pre.data(), pre.size() * sizeof(LeafPre), hipMemcpyHostToDevice));
+        }
+        w->accel.pre = w->d_pre;
         hipDeviceProp_t prop;
         int dev = 0;
         HIP_TRY(hipGetDevice(&dev));
@@ -397,6 +540,7 @@ void rth::wf2_destroy(Wf2* w) {
     if (!w) return;
     free_space(w);
     if (w->d_nodes) (void)hipFree(w->d_nodes);
+    if (w->d_pre) (void)hipFree(w->d_pre);
     delete w;
 }
 
@@ -453,6 +597,21 @@ int run_pipeline(const RtScene* scene, const Wf2* w, const Wf2Space& sp, size_t 
     else
         go(std::false_type{});
     HIP_TRY(hipGetLastError());
+#ifdef RT_WF2_PROFILE
+    if (std::getenv("RT_HIP_WF2_PROFILE")) {  // (the last batch's counters: the workspace is reset per batch)
+        Wf2Counters c;
+        HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(hipMemcpy(&c, sp.cnt, sizeof c, hipMemcpyDeviceToHost));
+        static const char* modes[4] = {"primary", "queue", "shadow", "containers"};
+        for (int m = 0; m < 4; ++m) {
+            const double tot = (double)(c.prof[m][0] + c.prof[m][1] + c.prof[m][2] + c.prof[m][3]);
+            if (tot <= 0.0) continue;
+            std::fprintf(stderr, "wf2 profile %-10s refill %.3f walk %.3f leaf %.3f finish %.3f | lanes in walk steps %.3f, lanes holding a leaf %.3f | Gcycles %.3f\n",
+                         modes[m], c.prof[m][0] / tot, c.prof[m][1] / tot, c.prof[m][2] / tot, c.prof[m][3] / tot,
+                         c.prof[m][5] ? (double)c.prof[m][4] / c.prof[m][5] : 0.0, c.prof[m][7] ? (double)c.prof[m][6] / c.prof[m][7] : 0.0, tot / 1e9);
+        }
+    }
+#endif
     return RT_OK;
 }
 
