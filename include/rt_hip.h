@@ -214,7 +214,9 @@ typedef struct RtSceneDesc {
     uint32_t n_dir_cands;
     const RtDirCand* dir_cands;
     uint32_t n_dir_entries;
-    const uint32_t* dir_cell_start; /* 6*dir_res^2 + 1 offsets into dir_entries */
+    const uint32_t* dir_cell_start; /* 6*dir_res^2 + 1 offsets into dir_entries; NULL (with n_dir_entries 0): candidates
+                                     * only -- rt_hip_scene_create builds the cells on the device, at a resolution of
+                                     * its choosing */
     const uint32_t* dir_entries;    /* candidate indices, grouped by cell         */
 } RtSceneDesc;
 
@@ -326,8 +328,9 @@ int rt_hip_render_rows_noalloc(const RtScene* scene, const RtCameraDesc* cam, ui
  * time; when they run out the affected hits keep their subtrees to themselves (mode-0 behaviour:
  * slower, same result).  The workspace belongs to the scene and is allocated -- with a device
  * synchronisation when it has to grow -- by the first launch that needs it: mode 1 about 640 B per
- * pixel of the frame; mode 2 about 460 B per pixel, at most ~4.5 GB (RT_HIP_WF_BUDGET_MB in the
- * environment): larger frames are rendered in batches of rows.  If it cannot be allocated the
+ * pixel of the frame; mode 2 about 460 B per pixel (4 GB at 4096 x 2160, 15 GB at 7680 x 4320), at most
+ * 24 GB and at most half of the device's free memory (RT_HIP_WF_BUDGET_MB in the environment sets the
+ * bound): larger frames are rendered in batches of rows.  If it cannot be allocated the
  * launch falls back to mode 0.
  * Replaces: nothing in the reference (tuning). */
 int rt_hip_scene_set_wavefront(RtScene* scene, int mode, uint64_t queue_items, uint64_t node_items);

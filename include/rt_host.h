@@ -125,7 +125,9 @@ int rth_camera_render(const RthCamera* cam, const RthWorld* w, double* out_rgb, 
 int rth_camera_render_rgb8(const RthCamera* cam, const RthWorld* w, uint8_t* out_rgb8, RtStats* stats_or_null);
 
 /* ---- flattened scene, for callers that keep it resident -------------------- */
-/* build_bvh: 0 no acceleration structures, 1 by policy, 2 one hierarchy per group level, 3 one world-space hierarchy */
+/* build_bvh: 0 no acceleration structures, 1 by policy, 2 one hierarchy per group level, 3 one world-space hierarchy;
+ * +8: the direction index's cells are rasterised here whatever the number of candidate conics (from 64 candidates on
+ * they are otherwise left to rt_hip_scene_create, which builds them on the device: RtSceneDesc.dir_cell_start null) */
 RthFlat* rth_world_flatten(const RthWorld* w, int build_bvh);
 const RtSceneDesc* rth_flat_desc(const RthFlat* f);
 void rth_flat_free(RthFlat* f);

@@ -387,17 +387,19 @@ class World(_Handle):
         N.host.rth_world_describe(self._p, _dp(out), n)
         return out
 
-    def flatten(self, build_bvh=True):
-        return FlatScene(self, build_bvh)
+    def flatten(self, build_bvh=True, host_cells=False):
+        return FlatScene(self, build_bvh, host_cells)
 
 
 class FlatScene(_Handle):
     """The flat record tables of include/rt_hip.h for one world (host memory)."""
     _free = N.host.rth_flat_free
 
-    def __init__(self, world, build_bvh=True):
+    def __init__(self, world, build_bvh=True, host_cells=False):
         # build_bvh: False / True (by policy), or "nested" / "global" to force one form of hierarchy
-        mode = {"nested": 2, "global": 3}.get(build_bvh, 1 if build_bvh else 0)
+        # host_cells: the direction index's cells rasterised by the flattener even for many candidates (otherwise
+        # scenes with >= 64 candidate conics leave them to rt_hip_scene_create, which builds them on the device)
+        mode = {"nested": 2, "global": 3}.get(build_bvh, 1 if build_bvh else 0) | (8 if host_cells else 0)
         super().__init__(N.host.rth_world_flatten(world._p, mode), "flatten")
         self.desc = N.host.rth_flat_desc(self._p)  # POINTER(RtSceneDesc), valid while self lives
 

@@ -283,16 +283,20 @@ int validate(const RtSceneDesc& d, uint32_t* flags_out) {
     }
     // direction index: offsets monotone and inside the entry list, entries name candidates,
     // candidates name a conic and the shape to evaluate for it (itself or an enclosing CSG)
+    // (dir_cell_start null: candidates only, the library builds the cells on the device)
     if (d.dir_res != 0) {
-        if (d.dir_res > 2048 || !d.dir_cell_start || !need(d.n_dir_cands, d.dir_cands) ||
-            !need(d.n_dir_entries, d.dir_entries))
+        if (d.dir_res > 2048 || !need(d.n_dir_cands, d.dir_cands)) return RT_ERR_INVALID_ARG;
+        if (d.dir_cell_start) {
+            if (!need(d.n_dir_entries, d.dir_entries)) return RT_ERR_INVALID_ARG;
+            const size_t n_cells = (size_t)6 * d.dir_res * d.dir_res;
+            if (d.dir_cell_start[0] != 0 || d.dir_cell_start[n_cells] != d.n_dir_entries) return RT_ERR_INVALID_SCENE;
+            for (size_t c = 0; c < n_cells; ++c)
+                if (d.dir_cell_start[c] > d.dir_cell_start[c + 1]) return RT_ERR_INVALID_SCENE;
+            for (uint32_t k = 0; k < d.n_dir_entries; ++k)
+                if (d.dir_entries[k] >= d.n_dir_cands) return RT_ERR_INVALID_SCENE;
+        } else if (d.n_dir_entries != 0 || d.dir_entries) {
             return RT_ERR_INVALID_ARG;
-        const size_t n_cells = (size_t)6 * d.dir_res * d.dir_res;
-        if (d.dir_cell_start[0] != 0 || d.dir_cell_start[n_cells] != d.n_dir_entries) return RT_ERR_INVALID_SCENE;
-        for (size_t c = 0; c < n_cells; ++c)
-            if (d.dir_cell_start[c] > d.dir_cell_start[c + 1]) return RT_ERR_INVALID_SCENE;
-        for (uint32_t k = 0; k < d.n_dir_entries; ++k)
-            if (d.dir_entries[k] >= d.n_dir_cands) return RT_ERR_INVALID_SCENE;
+        }
         for (uint32_t k = 0; k < d.n_dir_cands; ++k) {
             const RtDirCand& c = d.dir_cands[k];
             if (c.shape >= d.n_shapes || c.visit >= d.n_shapes) return RT_ERR_INVALID_SCENE;
@@ -674,10 +678,21 @@ int rt_hip_scene_create(const RtSceneDesc* desc, RtScene** out) {
     up(desc->bvh_nodes, desc->n_bvh_nodes, &bvh);
     RtDirCand* dir_cands = nullptr;
     uint32_t *dir_cell_start = nullptr, *dir_entries = nullptr;
+    uint32_t dir_res = desc->dir_res;
     if (desc->dir_res != 0) {
         up(desc->dir_cands, desc->n_dir_cands, &dir_cands);
-        up(desc->dir_cell_start, (size_t)6 * desc->dir_res * desc->dir_res + 1, &dir_cell_start);
-        up(desc->dir_entries, desc->n_dir_entries, &dir_entries);
+        if (desc->dir_cell_start) {
+            up(desc->dir_cell_start, (size_t)6 * desc->dir_res * desc->dir_res + 1, &dir_cell_start);
+            up(desc->dir_entries, desc->n_dir_entries, &dir_entries);
+        } else if (rc == RT_OK && desc->n_dir_cands != 0) {  // candidates only: the cells are built here, on the device
+            rth::DirIndex ix;
+            rc = rth::dir_index_build(dir_cands, desc->n_dir_cands, desc->dir_res, &ix);
+            if (rc == RT_OK) {
+                dir_cell_start = ix.d_cell_start, dir_entries = ix.d_entries, dir_res = ix.res;
+                s->allocations.push_back(ix.d_cell_start);
+                s->allocations.push_back(ix.d_entries);
+            }
+        }
     }
     if (rc == RT_OK) {
         const hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->d_status), sizeof(unsigned));
@@ -695,7 +710,7 @@ int rt_hip_scene_create(const RtSceneDesc* desc, RtScene** out) {
     s->dev.shapes = shapes, s->dev.conics = conics, s->dev.tris = tris, s->dev.groups = groups, s->dev.csgs = csgs;
     s->dev.lhit = lhit, s->dev.mats = mats, s->dev.pats = pats, s->dev.lights = lights, s->dev.bvh = bvh;
     s->dev.dir_cands = dir_cands, s->dev.dir_cell_start = dir_cell_start, s->dev.dir_entries = dir_entries;
-    s->dev.dir_res = desc->n_dir_cands ? desc->dir_res : 0u;
+    s->dev.dir_res = desc->n_dir_cands ? dir_res : 0u;
     s->dev.n_dir_cands = desc->n_dir_cands;
     s->dev.n_shapes = desc->n_shapes;
     s->dev.n_lights = desc->n_lights;

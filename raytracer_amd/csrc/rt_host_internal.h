@@ -53,6 +53,15 @@ int wf2_render_noalloc(const RtScene* scene, const RtCameraDesc* cam, uint32_t d
                        hipStream_t stream, RtStats* d_stats);
 // hipGetSymbolAddress of that array for the CURRENT device, once per device (rt_hip_init, or the first call that needs it)
 int scratch_init();
+// rt_dirindex.hip: the cell table of the direction index built on the current device from the candidates' quadratic
+// forms (blocking; default stream).  res_hint: the resolution the caller's tables were meant for; the library picks
+// its own from the number of candidates (RT_HIP_DIR_RES in the environment overrides).
+struct DirIndex {
+    uint32_t res, n_entries;
+    uint32_t *d_cell_start, *d_entries;
+};
+int dir_index_build(const RtDirCand* d_cands, uint32_t n_cands, uint32_t res_hint, DirIndex* out);
+void dir_index_free(DirIndex* ix);
 // rt_hip.hip: shade_hit's last line for the nodes of one generation (used by both wave-front forms)
 void launch_combine(const rtd::WfSpace& ws, unsigned level, double* d_out, hipStream_t stream);
 }  // namespace rth

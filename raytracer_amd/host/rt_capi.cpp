@@ -332,8 +332,10 @@ int rth_camera_render_rgb8(const RthCamera* cam, const RthWorld* w, uint8_t* out
 RthFlat* rth_world_flatten(const RthWorld* w, int build_bvh) {
     return guard([&] {
         FlattenOptions opt;
-        opt.build_bvh = build_bvh != 0;
-        opt.hierarchy = build_bvh >= 2 ? build_bvh - 1 : 0;  // 2: nested, 3: global
+        const int form = build_bvh & 7;
+        opt.build_bvh = form != 0;
+        opt.hierarchy = form >= 2 ? form - 1 : 0;  // 2: nested, 3: global
+        if (build_bvh & 8) opt.dir_device_min = static_cast<size_t>(-1);  // +8: the direction index's cells built here, whatever the count
         auto* f = new RthFlat{flatten(w->w, opt), {}};
         f->desc = f->flat.desc();
         return f;

@@ -2,7 +2,10 @@
 #include "rt_flatten.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <thread>
 #include <cstring>
 #include <map>
@@ -422,7 +425,8 @@ RtSceneDesc FlatScene::desc() const {
     d.dir_res = dir_res;
     d.n_dir_cands = static_cast<uint32_t>(dir_cands.size()), d.dir_cands = dir_cands.data();
     d.n_dir_entries = static_cast<uint32_t>(dir_entries.size()), d.dir_entries = dir_entries.data();
-    d.dir_cell_start = dir_cell_start.data();
+    d.dir_cell_start = dir_cell_start.empty() ? nullptr : dir_cell_start.data();  // null: the library builds the cells
+    if (dir_entries.empty()) d.dir_entries = nullptr;
     return d;
 }
 
@@ -476,7 +480,7 @@ void raster_cand(const RtDirCand& c, double qnorm, uint32_t cand, uint32_t res, 
     raster_cand(c, qnorm, cand, res, face, i0 + half, j0 + half, half, out);
 }
 
-void build_direction_index(FlatScene& f, uint32_t res) {
+void build_direction_index(FlatScene& f, uint32_t res, size_t device_min) {
     // res must be a power of two
     uint32_t r2 = 1;
     while (r2 * 2 <= res) r2 *= 2;
@@ -518,6 +522,10 @@ void build_direction_index(FlatScene& f, uint32_t res) {
         f.dir_cands.push_back(c);
     }
     if (f.dir_cands.empty()) return;
+    f.dir_res = res;
+    // many candidates: the cells are left to the library, which rasterises them on the device at a resolution of its
+    // choosing (rt_dirindex.hip; 2 526 candidates at 256 cells per edge: 100 ms on 16 host threads, < 1 ms there)
+    if (f.dir_cands.size() >= device_min) return;
     // candidates are rasterised independently: blocks of them on host threads, merged in candidate order
     // so that the table does not depend on the number of threads
     unsigned n_threads = std::thread::hardware_concurrency();
@@ -589,18 +597,25 @@ FlatScene flatten(const World& world, const FlattenOptions& opt) {
         }
     }
     f.global = opt.build_bvh && (opt.hierarchy == 2 || (opt.hierarchy == 0 && nested_groups && n_leaves >= opt.bvh_min_children && n_leaves < 64 * n_groups));
+    const bool timing = std::getenv("RT_FLATTEN_TIMING") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
+    auto t0 = now();
     std::vector<BvhItem> top;
     for (const Shape& s : world.shapes()) {
         const uint32_t idx = static_cast<uint32_t>(f.out.shapes.size());
         f.emit(s, -1, 0);
         if (opt.build_bvh && !f.global) top.push_back(BvhItem{tight_box(s, Matrix4::identity()), idx});
     }
+    if (timing) std::fprintf(stderr, "flatten: tables %.2f ms\n", ms_since(t0)), t0 = now();
     if (f.global) {
         if (!f.leaves.empty()) f.out.world_bvh_root = build_bvh(f.leaves, f.out.bvh_nodes);
     } else if (opt.build_bvh && f.wants_bvh(world.shapes().size(), world.shapes())) {
         f.out.world_bvh_root = build_bvh(top, f.out.bvh_nodes);
     }
-    if (opt.build_bvh && opt.dir_res > 0) build_direction_index(f.out, opt.dir_res);
+    if (timing) std::fprintf(stderr, "flatten: hierarchy %.2f ms\n", ms_since(t0)), t0 = now();
+    if (opt.build_bvh && opt.dir_res > 0) build_direction_index(f.out, opt.dir_res, opt.dir_device_min);
+    if (timing) std::fprintf(stderr, "flatten: direction index %.2f ms (%zu candidates, %zu entries)\n", ms_since(t0), f.out.dir_cands.size(), f.out.dir_entries.size());
     return std::move(f.out);
 }
 

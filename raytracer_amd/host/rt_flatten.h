@@ -39,6 +39,7 @@ struct FlattenOptions {
     int hierarchy = 0;
     size_t bvh_min_children = 8;  // groups smaller than this are scanned linearly
     uint32_t dir_res = 256;       // cube-map resolution of the direction index
+    size_t dir_device_min = 64;   // from this many candidates on, only the candidates are listed: the cells are built on the device
 };
 
 FlatScene flatten(const World& world, const FlattenOptions& opt = FlattenOptions());

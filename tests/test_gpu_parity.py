@@ -151,6 +151,47 @@ def test_conic_parallel_ray_branch_under_acceleration():
     assert not rel_mismatch(col, ow.color_at(rays, 2)).any()
 
 
+def test_direction_cells_built_on_the_device_equal_host_built_ones():
+    """From 64 candidate conics on the flattener lists the candidates only and rt_hip_scene_create rasterises the
+    direction cells on the device (rt_dirindex.hip).  Same frames as with the host-built table, in every mode; and the
+    parallel-ray bundle of the test above through 96 conics in one accelerated group."""
+    from raytracer_amd import Conic, Material, Matrix, PointLight, Primitive, World
+    world, cam = rt.synthetic(384, 216, 1500)
+    flat_dev, flat_host = world.flatten(), world.flatten(host_cells=True)
+    assert not flat_dev.desc.contents.dir_cell_start and flat_dev.desc.contents.n_dir_cands >= 64
+    assert flat_host.desc.contents.dir_cell_start and flat_host.desc.contents.n_dir_entries > 0
+    a, b = rt.DeviceScene(flat_dev), rt.DeviceScene(flat_host)
+    ref = _render_resident(b, cam, 0)
+    for mode in (0, 1, 2):
+        assert np.array_equal(_render_resident(a, cam, mode), ref), mode
+    a.close(), b.close()
+    prims = []
+    for i in range(96):
+        kind = Primitive.new_cylinder if i % 2 == 0 else Primitive.new_cone
+        lim = Conic(-0.5, 0.5, i % 3 == 0) if i % 2 == 0 else Conic(-1.0, -0.2, i % 3 == 0)
+        prims.append(kind(lim).with_transform(Matrix.chain(Matrix.translation(0.9 * (i % 12) - 5.0, 0.9 * (i // 12) - 3.0, 0.0),
+                                                           Matrix.rotation_x(np.pi / 2 + 0.01 * (i % 5)), Matrix.scaling(0.3, 0.3, 0.3)))
+                     .with_material(Material(color=(0.3 + 0.005 * i, 0.6, 0.4))))
+    world = World([rt.Compound.new_group(prims),
+                   Primitive.new_plane().with_transform(Matrix.chain(Matrix.translation(0, 0, 30), Matrix.rotation_x(np.pi / 2)))],
+                  [PointLight((-5, 8, -10), (1, 1, 1))])
+    assert not world.flatten().desc.contents.dir_cell_start
+    rng = np.random.default_rng(11)
+    n = 20000
+    o = np.stack([rng.uniform(-5.5, 5.5, n), rng.uniform(-3.5, 4.5, n), np.full(n, -8.0)], axis=1)
+    d = np.stack([rng.normal(0, 6e-3, n), rng.normal(0, 6e-3, n), np.ones(n)], axis=1)
+    d45 = np.stack([rng.normal(0, 2e-3, n), np.sin(np.pi / 4) + rng.normal(0, 3e-3, n), np.cos(np.pi / 4) + rng.normal(0, 3e-3, n)], axis=1)
+    d = np.concatenate([d, d45])
+    o = np.concatenate([o, o])
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([o, d], axis=1)
+    ow = orc.OracleWorld(world.describe())
+    got, ref = world.probe(rays), ow.probe(rays)
+    assert np.array_equal(got[:, [0, 2]], ref[:, [0, 2]])
+    assert not rel_mismatch(got, ref, 1e-12, 1e-15).any()
+    assert not rel_mismatch(world.color_at(rays, 2), ow.color_at(rays, 2)).any()
+
+
 def _render_resident(scene, cam, mode, queue_items=0, node_items=0, with_stats=False):
     import ctypes as C
     import torch
