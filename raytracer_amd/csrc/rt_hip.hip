@@ -310,66 +310,6 @@ int validate(const RtSceneDesc& d, uint32_t* flags_out) {
     return RT_OK;
 }
 
-// Device -> caller's (pageable) buffer for the host-buffer entry points.  A plain hipMemcpy into pageable
-// memory runs at ~9 GB/s; here the DMA goes into a pinned staging buffer the library keeps (chunks, ~55 GB/s)
-// while host threads move finished chunks on to the caller's buffer.
-std::mutex g_staging_mutex;
-void* g_staging = nullptr;
-size_t g_staging_bytes = 0;
-
-int copy_to_host(void* dst, const void* d_src, size_t bytes) {
-    if (bytes < (8u << 20)) {  // small: not worth the machinery
-        HIP_TRY(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
-        return RT_OK;
-    }
-    std::lock_guard<std::mutex> lock(g_staging_mutex);
-    if (g_staging_bytes < bytes) {
-        if (g_staging) (void)hipHostFree(g_staging);
-        g_staging = nullptr, g_staging_bytes = 0;
-        if (hipHostMalloc(&g_staging, bytes, hipHostMallocDefault) != hipSuccess) {  // no pinned memory to be had
-            (void)hipGetLastError();
-            g_staging = nullptr;
-            HIP_TRY(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
-            return RT_OK;
-        }
-        g_staging_bytes = bytes;
-    }
-    constexpr size_t kChunk = 16u << 20;
-    const size_t n_chunks = (bytes + kChunk - 1) / kChunk;
-    HIP_TRY(hipDeviceSynchronize());  // the frame was written on the default stream
-    hipStream_t stream = nullptr;
-    HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-    std::vector<hipEvent_t> done(n_chunks, nullptr);
-    int rc = RT_OK;
-    for (size_t k = 0; k < n_chunks && rc == RT_OK; ++k) {
-        const size_t off = k * kChunk, len = bytes - off < kChunk ? bytes - off : kChunk;
-        if (hipMemcpyAsync(static_cast<char*>(g_staging) + off, static_cast<const char*>(d_src) + off, len,
-                           hipMemcpyDeviceToHost, stream) != hipSuccess ||
-            hipEventCreateWithFlags(&done[k], hipEventDisableTiming) != hipSuccess ||
-            hipEventRecord(done[k], stream) != hipSuccess)
-            rc = hip_fail(hipGetLastError(), "staged device-to-host copy");
-    }
-    const unsigned n_threads = 4;
-    for (size_t k = 0; k < n_chunks && rc == RT_OK; ++k) {
-        if (hipEventSynchronize(done[k]) != hipSuccess) {
-            rc = hip_fail(hipGetLastError(), "hipEventSynchronize");
-            break;
-        }
-        const size_t off = k * kChunk, len = bytes - off < kChunk ? bytes - off : kChunk;
-        std::vector<std::thread> pool;
-        for (unsigned t = 0; t < n_threads; ++t) {
-            const size_t a = off + len * t / n_threads, b = off + len * (t + 1) / n_threads;
-            pool.emplace_back([=] { std::memcpy(static_cast<char*>(dst) + a, static_cast<const char*>(g_staging) + a, b - a); });
-        }
-        for (std::thread& th : pool) th.join();
-    }
-    (void)hipStreamSynchronize(stream);
-    for (hipEvent_t e : done)
-        if (e) (void)hipEventDestroy(e);
-    (void)hipStreamDestroy(stream);
-    return rc;
-}
-
 }  // namespace
 
 
@@ -603,11 +543,7 @@ int rt_hip_init(int device) {
 }
 
 void rt_hip_shutdown(void) {
-    {
-        std::lock_guard<std::mutex> staging_lock(g_staging_mutex);
-        if (g_staging) (void)hipHostFree(g_staging);
-        g_staging = nullptr, g_staging_bytes = 0;
-    }
+    rth::hostmem_shutdown();
     std::lock_guard<std::mutex> lock(g_mutex);
     g_initialised = false;
     g_device = -1;
@@ -647,6 +583,8 @@ int rt_hip_scene_create(const RtSceneDesc* desc, RtScene** out) {
     std::memset(&s->dev, 0, sizeof s->dev);
     s->d_status = nullptr;
     s->d_dev = nullptr;
+    s->tables = nullptr;
+    for (hipEvent_t& e : s->band_done) e = nullptr;
     if (hipGetDevice(&s->device) != hipSuccess) s->device = g_device;  // the calling thread's current device
     std::memset(&s->wf, 0, sizeof s->wf);
     s->wf_pixels = 0;
@@ -656,69 +594,39 @@ int rt_hip_scene_create(const RtSceneDesc* desc, RtScene** out) {
     s->wf2 = nullptr;
     for (uint32_t k = 0; k < desc->n_materials; ++k)  // world.rs:99,110: these are the only tests that let color_at recurse
         if (desc->materials[k].reflective != 0.0 || desc->materials[k].transparency != 0.0) flags |= RT_SCENE_RECURSIVE;
+    // Every table, the LDS staging image, the pipeline's hierarchy, the scene record and the status word in ONE device
+    // block, filled by one host-to-device copy (the block comes from the library's cache: the drop-in pattern of a
+    // scene per frame does not reach the driver's allocator after its first frame).
+    rth::Arena arena;
     int rc = RT_OK;
-    auto up = [&](auto* src, size_t n, auto** dst) {
-        if (rc != RT_OK) return;
-        rc = upload(src, n, dst);
-        if (*dst) s->allocations.push_back((void*)*dst);
-    };
-    RtShape* shapes; RtConic* conics; RtTriangle* tris; RtGroup* groups; RtCsg* csgs; uint8_t* lhit;
-    RtMaterial* mats; RtPattern* pats; RtLight* lights; RtBvhNode* bvh;
-    shapes = nullptr, conics = nullptr, tris = nullptr, groups = nullptr, csgs = nullptr, lhit = nullptr;
-    mats = nullptr, pats = nullptr, lights = nullptr, bvh = nullptr;
-    up(desc->shapes, desc->n_shapes, &shapes);
-    up(desc->conics, desc->n_conics, &conics);
-    up(desc->triangles, desc->n_triangles, &tris);
-    up(desc->groups, desc->n_groups, &groups);
-    up(desc->csgs, desc->n_csgs, &csgs);
-    up(desc->lhit, desc->n_lhit, &lhit);
-    up(desc->materials, desc->n_materials, &mats);
-    up(desc->patterns, desc->n_patterns, &pats);
-    up(desc->lights, desc->n_lights, &lights);
-    up(desc->bvh_nodes, desc->n_bvh_nodes, &bvh);
-    RtDirCand* dir_cands = nullptr;
-    uint32_t *dir_cell_start = nullptr, *dir_entries = nullptr;
-    uint32_t dir_res = desc->dir_res;
-    if (desc->dir_res != 0) {
-        up(desc->dir_cands, desc->n_dir_cands, &dir_cands);
+    const size_t o_shapes = arena.add(desc->shapes, sizeof(RtShape) * desc->n_shapes);
+    const size_t o_conics = arena.add(desc->conics, sizeof(RtConic) * desc->n_conics);
+    const size_t o_tris = arena.add(desc->triangles, sizeof(RtTriangle) * desc->n_triangles);
+    const size_t o_groups = arena.add(desc->groups, sizeof(RtGroup) * desc->n_groups);
+    const size_t o_csgs = arena.add(desc->csgs, sizeof(RtCsg) * desc->n_csgs);
+    const size_t o_lhit = arena.add(desc->lhit, desc->n_lhit);
+    const size_t o_mats = arena.add(desc->materials, sizeof(RtMaterial) * desc->n_materials);
+    const size_t o_pats = arena.add(desc->patterns, sizeof(RtPattern) * desc->n_patterns);
+    const size_t o_lights = arena.add(desc->lights, sizeof(RtLight) * desc->n_lights);
+    const size_t o_bvh = arena.add(desc->bvh_nodes, sizeof(RtBvhNode) * desc->n_bvh_nodes);
+    size_t o_cands = 0, o_cells = 0, o_entries = 0;
+    const bool has_dir = desc->dir_res != 0 && desc->n_dir_cands != 0;
+    if (has_dir) {
+        o_cands = arena.add(desc->dir_cands, sizeof(RtDirCand) * desc->n_dir_cands);
         if (desc->dir_cell_start) {
-            up(desc->dir_cell_start, (size_t)6 * desc->dir_res * desc->dir_res + 1, &dir_cell_start);
-            up(desc->dir_entries, desc->n_dir_entries, &dir_entries);
-        } else if (rc == RT_OK && desc->n_dir_cands != 0) {  // candidates only: the cells are built here, on the device
-            rth::DirIndex ix;
-            rc = rth::dir_index_build(dir_cands, desc->n_dir_cands, desc->dir_res, &ix);
-            if (rc == RT_OK) {
-                dir_cell_start = ix.d_cell_start, dir_entries = ix.d_entries, dir_res = ix.res;
-                s->allocations.push_back(ix.d_cell_start);
-                s->allocations.push_back(ix.d_entries);
-            }
+            o_cells = arena.add(desc->dir_cell_start, sizeof(uint32_t) * ((size_t)6 * desc->dir_res * desc->dir_res + 1));
+            o_entries = arena.add(desc->dir_entries, sizeof(uint32_t) * desc->n_dir_entries);
         }
     }
-    if (rc == RT_OK) {
-        const hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->d_status), sizeof(unsigned));
-        if (e != hipSuccess) rc = hip_fail(e, "hipMalloc(status)");
-        else {
-            s->allocations.push_back(s->d_status);
-            const hipError_t e2 = hipMemset(s->d_status, 0, sizeof(unsigned));
-            if (e2 != hipSuccess) rc = hip_fail(e2, "hipMemset(status)");
-        }
-    }
-    if (rc != RT_OK) {
-        rt_hip_scene_destroy(s);
-        return rc;
-    }
-    s->dev.shapes = shapes, s->dev.conics = conics, s->dev.tris = tris, s->dev.groups = groups, s->dev.csgs = csgs;
-    s->dev.lhit = lhit, s->dev.mats = mats, s->dev.pats = pats, s->dev.lights = lights, s->dev.bvh = bvh;
-    s->dev.dir_cands = dir_cands, s->dev.dir_cell_start = dir_cell_start, s->dev.dir_entries = dir_entries;
-    s->dev.dir_res = desc->n_dir_cands ? dir_res : 0u;
-    s->dev.n_dir_cands = desc->n_dir_cands;
+    s->dev.n_dir_cands = has_dir ? desc->n_dir_cands : 0u;
+    s->dev.dir_res = has_dir ? desc->dir_res : 0u;
     s->dev.n_shapes = desc->n_shapes;
     s->dev.n_lights = desc->n_lights;
     s->dev.world_bvh_root = desc->world_bvh_root;
     s->dev.flags = flags;
-    s->dev.g_shapes = shapes, s->dev.g_conics = conics, s->dev.g_tris = tris;
     s->dev.stage = nullptr;
     s->dev.stage_bytes = 0;
+    size_t o_stage = 0;
     {  // pack the tables lanes index individually: small scenes trace and shade out of an LDS copy
         const bool is_flat = (flags & RT_SCENE_FLAT) != 0;
         std::vector<unsigned char> image;
@@ -728,42 +636,84 @@ int rt_hip_scene_create(const RtSceneDesc* desc, RtScene** out) {
             if (bytes) image.insert(image.end(), b, b + bytes);
             while (image.size() % 16u) image.push_back(0);
         };
-        put(desc->shapes, sizeof(RtShape) * desc->n_shapes, &s->dev.stage_off[0]);
-        put(desc->conics, sizeof(RtConic) * desc->n_conics, &s->dev.stage_off[1]);
-        put(desc->materials, sizeof(RtMaterial) * desc->n_materials, &s->dev.stage_off[2]);
-        put(desc->patterns, sizeof(RtPattern) * desc->n_patterns, &s->dev.stage_off[3]);
-        put(desc->lights, sizeof(RtLight) * desc->n_lights, &s->dev.stage_off[4]);
-        if (!is_flat) {  // what the traversal of compounds reads (FLAT kernels fetch triangles through the scalar cache)
-            put(desc->groups, sizeof(RtGroup) * desc->n_groups, &s->dev.stage_off[5]);
-            put(desc->csgs, sizeof(RtCsg) * desc->n_csgs, &s->dev.stage_off[6]);
-            put(desc->lhit, desc->n_lhit, &s->dev.stage_off[7]);
-            put(desc->bvh_nodes, sizeof(RtBvhNode) * desc->n_bvh_nodes, &s->dev.stage_off[8]);
-            put(desc->triangles, sizeof(RtTriangle) * desc->n_triangles, &s->dev.stage_off[9]);
-        }
         uint64_t world_hits = 0;  // most entries World::intersections can return: the per-lane list must hold them
         for (uint32_t i = 0; i < desc->n_shapes; ++i) world_hits += max_hits_of_kind(RT_KIND(desc->shapes[i].kind_flags));
-        const bool fits = is_flat ? image.size() <= RT_STAGE_MAX_BYTES && world_hits <= RT_LDS_LIST_CAP
-                                  : image.size() <= RT_STAGE_MAX_BYTES_COMPOUND;
-        if (!image.empty() && fits) {
-            s->dev.lds_list_cap = !is_flat ? 0u : (world_hits ? (uint32_t)world_hits : 1u);
-            unsigned char* d_image = nullptr;
-            rc = upload(image.data(), image.size(), &d_image);
-            if (d_image) s->allocations.push_back(d_image);
-            s->dev.stage = d_image;
-            s->dev.stage_bytes = rc == RT_OK ? (uint32_t)image.size() : 0u;
+        size_t bytes = sizeof(RtShape) * desc->n_shapes + sizeof(RtConic) * desc->n_conics + sizeof(RtMaterial) * desc->n_materials +
+                       sizeof(RtPattern) * desc->n_patterns + sizeof(RtLight) * desc->n_lights;
+        if (!is_flat)
+            bytes += sizeof(RtGroup) * desc->n_groups + sizeof(RtCsg) * desc->n_csgs + desc->n_lhit + sizeof(RtBvhNode) * desc->n_bvh_nodes +
+                     sizeof(RtTriangle) * desc->n_triangles;
+        const bool may_fit = is_flat ? bytes <= RT_STAGE_MAX_BYTES && world_hits <= RT_LDS_LIST_CAP : bytes <= RT_STAGE_MAX_BYTES_COMPOUND;
+        if (may_fit) {  // (large scenes do not pay for an image they will not use)
+            put(desc->shapes, sizeof(RtShape) * desc->n_shapes, &s->dev.stage_off[0]);
+            put(desc->conics, sizeof(RtConic) * desc->n_conics, &s->dev.stage_off[1]);
+            put(desc->materials, sizeof(RtMaterial) * desc->n_materials, &s->dev.stage_off[2]);
+            put(desc->patterns, sizeof(RtPattern) * desc->n_patterns, &s->dev.stage_off[3]);
+            put(desc->lights, sizeof(RtLight) * desc->n_lights, &s->dev.stage_off[4]);
+            if (!is_flat) {  // what the traversal of compounds reads (FLAT kernels fetch triangles through the scalar cache)
+                put(desc->groups, sizeof(RtGroup) * desc->n_groups, &s->dev.stage_off[5]);
+                put(desc->csgs, sizeof(RtCsg) * desc->n_csgs, &s->dev.stage_off[6]);
+                put(desc->lhit, desc->n_lhit, &s->dev.stage_off[7]);
+                put(desc->bvh_nodes, sizeof(RtBvhNode) * desc->n_bvh_nodes, &s->dev.stage_off[8]);
+                put(desc->triangles, sizeof(RtTriangle) * desc->n_triangles, &s->dev.stage_off[9]);
+            }
+            const bool fits = is_flat ? image.size() <= RT_STAGE_MAX_BYTES && world_hits <= RT_LDS_LIST_CAP
+                                      : image.size() <= RT_STAGE_MAX_BYTES_COMPOUND;
+            if (!image.empty() && fits) {
+                s->dev.lds_list_cap = !is_flat ? 0u : (world_hits ? (uint32_t)world_hits : 1u);
+                o_stage = arena.add(image.data(), image.size());
+                s->dev.stage_bytes = (uint32_t)image.size();
+            }
         }
     }
+    rc = rth::wf2_create(*desc, flags, arena, &s->wf2);
+    if (rc != RT_OK) {
+        rt_hip_scene_destroy(s);
+        return rc;
+    }
+    const size_t o_record = arena.reserve(sizeof(SceneDev));
+    const size_t o_status = arena.reserve(sizeof(unsigned));
     {
-        const hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->d_dev), sizeof(SceneDev));
-        if (e != hipSuccess) {
-            rc = hip_fail(e, "hipMalloc(scene record)");
-        } else {
-            s->allocations.push_back(s->d_dev);
-            const hipError_t e2 = hipMemcpy(s->d_dev, &s->dev, sizeof(SceneDev), hipMemcpyHostToDevice);
-            if (e2 != hipSuccess) rc = hip_fail(e2, "hipMemcpy(scene record)");
+        void* block = nullptr;
+        rc = rth::block_alloc(&block, arena.host.size());
+        if (rc != RT_OK) {
+            rt_hip_scene_destroy(s);
+            return rc;
+        }
+        s->tables = static_cast<unsigned char*>(block);
+    }
+    unsigned char* base = s->tables;
+    auto at = [&](size_t off, auto* type_tag) { return reinterpret_cast<decltype(type_tag)>(base + off); };
+    s->dev.shapes = at(o_shapes, (const RtShape*)nullptr), s->dev.conics = at(o_conics, (const RtConic*)nullptr);
+    s->dev.tris = at(o_tris, (const RtTriangle*)nullptr), s->dev.groups = at(o_groups, (const RtGroup*)nullptr);
+    s->dev.csgs = at(o_csgs, (const RtCsg*)nullptr), s->dev.lhit = at(o_lhit, (const uint8_t*)nullptr);
+    s->dev.mats = at(o_mats, (const RtMaterial*)nullptr), s->dev.pats = at(o_pats, (const RtPattern*)nullptr);
+    s->dev.lights = at(o_lights, (const RtLight*)nullptr), s->dev.bvh = at(o_bvh, (const RtBvhNode*)nullptr);
+    s->dev.g_shapes = s->dev.shapes, s->dev.g_conics = s->dev.conics, s->dev.g_tris = s->dev.tris;
+    s->dev.dir_cands = has_dir ? at(o_cands, (const RtDirCand*)nullptr) : nullptr;
+    s->dev.dir_cell_start = has_dir && desc->dir_cell_start ? at(o_cells, (const uint32_t*)nullptr) : nullptr;
+    s->dev.dir_entries = has_dir && desc->dir_cell_start ? at(o_entries, (const uint32_t*)nullptr) : nullptr;
+    if (s->dev.stage_bytes) s->dev.stage = base + o_stage;
+    s->d_dev = reinterpret_cast<SceneDev*>(base + o_record);
+    s->d_status = reinterpret_cast<unsigned*>(base + o_status);
+    rth::wf2_bind(s->wf2, base);
+    const bool cells_here = has_dir && !desc->dir_cell_start;
+    if (!cells_here) std::memcpy(arena.host.data() + o_record, &s->dev, sizeof(SceneDev));
+    {
+        const hipError_t e = hipMemcpy(base, arena.host.data(), arena.host.size(), hipMemcpyHostToDevice);
+        if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy(scene tables)");
+    }
+    if (rc == RT_OK && cells_here) {  // candidates only: the cells are built here, on the device (rt_dirindex.hip)
+        rth::DirIndex ix;
+        rc = rth::dir_index_build(s->dev.dir_cands, desc->n_dir_cands, desc->dir_res, &ix);
+        if (rc == RT_OK) {
+            s->dev.dir_cell_start = ix.d_cell_start, s->dev.dir_entries = ix.d_entries, s->dev.dir_res = ix.res;
+            s->allocations.push_back(ix.d_cell_start);
+            s->allocations.push_back(ix.d_entries);
+            const hipError_t e = hipMemcpy(s->d_dev, &s->dev, sizeof(SceneDev), hipMemcpyHostToDevice);
+            if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy(scene record)");
         }
     }
-    if (rc == RT_OK) rc = rth::wf2_create(*desc, flags, &s->wf2);
     if (rc != RT_OK) {
         rt_hip_scene_destroy(s);
         return rc;
@@ -775,9 +725,12 @@ int rt_hip_scene_create(const RtSceneDesc* desc, RtScene** out) {
 void rt_hip_scene_destroy(RtScene* scene) {
     if (!scene) return;
     DeviceGuard device_guard(scene->device);
+    (void)hipDeviceSynchronize();  // nothing of this scene's may still be running when its blocks are handed on
     for (void* p : scene->allocations) (void)hipFree(p);
-    if (scene->d_frame) (void)hipFree(scene->d_frame);
-    if (scene->d_frame8) (void)hipFree(scene->d_frame8);
+    rth::block_free(scene->tables);
+    rth::block_free(scene->d_frame);
+    for (hipEvent_t e : scene->band_done)
+        if (e) (void)hipEventDestroy(e);
     for (void* p : {(void*)scene->wf.queue[0], (void*)scene->wf.queue[1], (void*)scene->wf.nodes, (void*)scene->wf.shards})
         if (p) (void)hipFree(p);
     rth::wf2_destroy(scene->wf2);
@@ -852,17 +805,23 @@ static int scene_render_to_host(const RtScene* scene, const RtCameraDesc* cam, u
     if (crc0 != RT_OK) return crc0;
     const size_t n_values = (size_t)cam->hsize * cam->vsize * 3u;
     if (scene->frame_values < n_values) {
-        if (scene->d_frame) (void)hipFree(scene->d_frame);
-        if (scene->d_frame8) (void)hipFree(scene->d_frame8);
+        rth::block_free(scene->d_frame);
         scene->d_frame = nullptr, scene->d_frame8 = nullptr, scene->frame_values = 0;
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&scene->d_frame), n_values * sizeof(double)));
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&scene->d_frame8), n_values));
+        void* block = nullptr;  // one block: the f64 frame, then its 8-bit form
+        const int brc = rth::block_alloc(&block, n_values * sizeof(double) + n_values);
+        if (brc != RT_OK) return brc;
+        scene->d_frame = static_cast<double*>(block);
+        scene->d_frame8 = reinterpret_cast<uint8_t*>(scene->d_frame + n_values);
         scene->frame_values = n_values;
     }
     double* d_out = scene->d_frame;
     uint8_t* d_out8 = scene->d_frame8;
     RtStats* d_stats = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
+    constexpr uint32_t kFrameBands = RtScene::kFrameBands;
+    hipEvent_t* band_done = scene->band_done;
+    for (uint32_t k = 0; k < kFrameBands; ++k)
+        if (!band_done[k]) HIP_TRY(hipEventCreateWithFlags(&band_done[k], hipEventDisableTiming));
     auto body = [&]() -> int {
         if (stats) {
             HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_stats), sizeof(RtStats)));
@@ -871,18 +830,36 @@ static int scene_render_to_host(const RtScene* scene, const RtCameraDesc* cam, u
             HIP_TRY(hipEventCreate(&e1));
             HIP_TRY(hipEventRecord(e0, nullptr));
         }
-        const RowMap rows{0u, 1u, cam->vsize, cam->vsize};
-        const int lrc = launch_render(scene, cam, depth, rows, d_out, nullptr, d_stats);
-        if (lrc != RT_OK) return lrc;
+        // A large f64 frame of a one-launch scene goes out in four bands of rows: band k crosses PCIe while band
+        // k + 1 is traced (the kernel pipeline's frames stay whole: its batches are better large, and its frames take
+        // longer than their copy anyway).
+        const bool pipeline = scene->wf2 && (scene->dev.flags & RT_SCENE_RECURSIVE) && depth > 0 && scene->wf_mode != 0 && scene->wf_mode != 1;
+        const uint32_t n_bands = out_rgb && !pipeline && n_values * sizeof(double) >= ((size_t)64 << 20) && cam->vsize >= 256u ? kFrameBands : 1u;
+        const uint32_t band_rows = (cam->vsize + n_bands - 1u) / n_bands;
+        for (uint32_t k = 0; k < n_bands; ++k) {
+            const uint32_t r0 = k * band_rows, r1 = r0 + band_rows < cam->vsize ? r0 + band_rows : cam->vsize;
+            if (r0 >= r1) break;
+            const RowMap rows{k, n_bands, band_rows, r1 - r0};
+            const int lrc = launch_render(scene, cam, depth, rows, d_out + (size_t)r0 * cam->hsize * 3u, nullptr, d_stats);
+            if (lrc != RT_OK) return lrc;
+            if (n_bands > 1u) HIP_TRY(hipEventRecord(band_done[k], nullptr));
+        }
         if (stats) HIP_TRY(hipEventRecord(e1, nullptr));
         if (out_rgb8) {  // quantise on the device: an eighth of the bytes cross PCIe
             const int qrc = rt_hip_quantize(d_out, n_values, d_out8, nullptr);
             if (qrc != RT_OK) return qrc;
-            const int crc = copy_to_host(out_rgb8, d_out8, n_values);
-            if (crc != RT_OK) return crc;
         }
         if (out_rgb) {
-            const int crc = copy_to_host(out_rgb, d_out, n_values * sizeof(double));
+            for (uint32_t k = 0; k < n_bands; ++k) {
+                const uint32_t r0 = k * band_rows, r1 = r0 + band_rows < cam->vsize ? r0 + band_rows : cam->vsize;
+                if (r0 >= r1) break;
+                const size_t off = (size_t)r0 * cam->hsize * 3u, n = (size_t)(r1 - r0) * cam->hsize * 3u;
+                const int crc = rth::copy_to_host(out_rgb + off, d_out + off, n * sizeof(double), nullptr, n_bands > 1u ? band_done[k] : nullptr);
+                if (crc != RT_OK) return crc;
+            }
+        }
+        if (out_rgb8) {
+            const int crc = rth::copy_to_host(out_rgb8, d_out8, n_values, nullptr);
             if (crc != RT_OK) return crc;
         }
         const int src = read_status(scene, nullptr);

@@ -14,8 +14,8 @@ using namespace rtd;
 using namespace rtk;
 
 struct Wf2 {
-    LeafPre* d_pre = nullptr;
-    Bvh4Node* d_nodes = nullptr;
+    size_t off_nodes = 0, off_pre = 0;  // the hierarchy and the leaf records inside the scene's block of tables
+    bool has_pre = false;
     Wf2Accel accel{};
     uint32_t n_nodes = 0, stack_need = 0;
     // workspace, grown to the largest batch asked for; launches on one scene are ordered by the caller
@@ -406,7 +406,7 @@ int ensure_space(Wf2* w, size_t items, size_t q_items, size_t node_items, uint32
 
 }  // namespace
 
-int rth::wf2_create(const RtSceneDesc& d, uint32_t scene_flags, Wf2** out) {
+int rth::wf2_create(const RtSceneDesc& d, uint32_t scene_flags, Arena& arena, Wf2** out) {
     *out = nullptr;
     // What the pipeline covers: a world-level hierarchy whose leaves are primitives (nested in groups or not), no CSG
     // node and no shadowless primitive anywhere (those need the sorted world list per ray: the older kernels have it).
@@ -510,29 +510,42 @@ int rth::wf2_create(const RtSceneDesc& d, uint32_t scene_flags, Wf2** out) {
     w->accel.slack = (1.0f / 1048576.0f) * (float)env_or("RT_HIP_WF2_SLACK", 1u, 1u, 1u << 20);
     w->accel.seg_near = env_or("RT_HIP_WF2_SEG_NEAR", 0u, 0u, 1u) ? -1e-2f : -INFINITY;
     w->n_nodes = (uint32_t)b.nodes.size();
+    w->off_nodes = arena.add(b.nodes.data(), b.nodes.size() * sizeof(Bvh4Node));
+    arena.reserve(sizeof(Bvh4Node));  // (one node of slack after the table)
+    const char* pre_env = std::getenv("RT_HIP_WF2_PRE");
+    w->has_pre = !(pre_env && *pre_env == '0');
+    if (w->has_pre) {
+        w->off_pre = arena.add(pre.data(), pre.size() * sizeof(LeafPre));
+        arena.reserve(sizeof(LeafPre));
+    }
     auto body = [&]() -> int {
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->d_nodes), (b.nodes.size() + 1) * sizeof(Bvh4Node)));
-        if (!b.nodes.empty())
-            HIP_TRY(hipMemcpy(w->d_nodes, b.nodes.data(), b.nodes.size() * sizeof(Bvh4Node), hipMemcpyHostToDevice));
-        w->accel.nodes = w->d_nodes;
-        const char* pre_env = std::getenv("RT_HIP_WF2_PRE");
-        if (!(pre_env && *pre_env == '0')) {
-            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w->d_pre), (pre.size() + 1) * sizeof(LeafPre)));
-            HIP_TRY(hipMemcpy(w->d_pre, pre.data(), pre.size() * sizeof(LeafPre), hipMemcpyHostToDevice));
-        }
-        w->accel.pre = w->d_pre;
-        hipDeviceProp_t prop;
+        // the device's compute units and how many one-wave blocks of each traversal kernel one of them holds: asked once per device
+        static std::mutex m;
+        struct PerDevice {
+            bool known = false;
+            int n_cus = 0;
+            int blocks[2][4] = {};
+        };
+        static PerDevice known[64];
         int dev = 0;
         HIP_TRY(hipGetDevice(&dev));
-        HIP_TRY(hipGetDeviceProperties(&prop, dev));
-        w->n_cus = prop.multiProcessorCount;
-        int rc = RT_OK;
-#define RT_OCC(ST, MODE) if (rc == RT_OK) rc = occupancy(wf2_trace_kernel<ST, MODE>, &w->trace_blocks_per_cu[ST ? 1 : 0][MODE]);
-        RT_OCC(false, WF2_PRIMARY) RT_OCC(false, WF2_QUEUE) RT_OCC(false, WF2_SHADOW)
-        RT_OCC(true, WF2_PRIMARY) RT_OCC(true, WF2_QUEUE) RT_OCC(true, WF2_SHADOW)
-        RT_OCC(false, WF2_CONTAINERS) RT_OCC(true, WF2_CONTAINERS)
+        std::lock_guard<std::mutex> lock(m);
+        PerDevice local;
+        PerDevice& pd = dev >= 0 && dev < 64 ? known[dev] : local;
+        if (!pd.known) {
+            HIP_TRY(hipDeviceGetAttribute(&pd.n_cus, hipDeviceAttributeMultiprocessorCount, dev));
+            int rc = RT_OK;
+#define RT_OCC(ST, MODE) if (rc == RT_OK) rc = occupancy(wf2_trace_kernel<ST, MODE>, &pd.blocks[ST ? 1 : 0][MODE]);
+            RT_OCC(false, WF2_PRIMARY) RT_OCC(false, WF2_QUEUE) RT_OCC(false, WF2_SHADOW)
+            RT_OCC(true, WF2_PRIMARY) RT_OCC(true, WF2_QUEUE) RT_OCC(true, WF2_SHADOW)
+            RT_OCC(false, WF2_CONTAINERS) RT_OCC(true, WF2_CONTAINERS)
 #undef RT_OCC
-        return rc;
+            if (rc != RT_OK) return rc;
+            pd.known = true;
+        }
+        w->n_cus = pd.n_cus;
+        std::memcpy(w->trace_blocks_per_cu, pd.blocks, sizeof pd.blocks);
+        return RT_OK;
     };
     const int rc = body();
     if (rc != RT_OK) {
@@ -546,9 +559,13 @@ int rth::wf2_create(const RtSceneDesc& d, uint32_t scene_flags, Wf2** out) {
 void rth::wf2_destroy(Wf2* w) {
     if (!w) return;
     free_space(w);
-    if (w->d_nodes) (void)hipFree(w->d_nodes);
-    if (w->d_pre) (void)hipFree(w->d_pre);
     delete w;
+}
+
+void rth::wf2_bind(Wf2* w, unsigned char* base) {
+    if (!w) return;
+    w->accel.nodes = reinterpret_cast<const Bvh4Node*>(base + w->off_nodes);
+    w->accel.pre = w->has_pre ? reinterpret_cast<const LeafPre*>(base + w->off_pre) : nullptr;
 }
 
 namespace {

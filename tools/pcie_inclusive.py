@@ -20,6 +20,32 @@ for name in ("pattern", "glass_bubble"):
     t, _ = best(lambda: cam.render(world))
     print(f"{name} 4096x2160 via rt_hip_render (flatten + scene upload + kernel + 212 MB f64 frame to the caller's pageable buffer): "
           f"{t*1e3:.1f} ms wall, {rays/t/1e6:.0f} Mrays/s PCIe-inclusive")
+    # the C ABI call alone: tables already flattened, the caller's buffer already touched (as a Canvas's Vec is)
+    import ctypes as C
+    from raytracer_amd import _native as N
+    flat = world.flatten()
+    cd = cam.desc()
+    buf = np.zeros((cam.v_size, cam.h_size, 3))
+    buf8 = np.zeros((cam.v_size, cam.h_size, 3), dtype=np.uint8)
+    def call():
+        N.check(N.hip.rt_hip_render(flat.desc, C.byref(cd), 5, buf.ctypes.data_as(C.POINTER(C.c_double)), None), "rt_hip_render")
+    def call8():
+        N.check(N.hip.rt_hip_render_rgb8(flat.desc, C.byref(cd), 5, buf8.ctypes.data_as(C.POINTER(C.c_uint8)), None), "rt_hip_render_rgb8")
+    call(); call8()
+    tc, _ = best(call, 5)
+    tc8, _ = best(call8, 5)
+    assert np.array_equal(buf, img.pixels)
+    print(f"  rt_hip_render alone (tables flattened, caller's buffer touched): {tc*1e3:.2f} ms f64, {tc8*1e3:.2f} ms rgb8")
+    scene = rt.DeviceScene(flat)
+    def res():
+        N.check(N.hip.rt_hip_scene_render(scene._p, C.byref(cd), 5, buf.ctypes.data_as(C.POINTER(C.c_double)), None), "rt_hip_scene_render")
+    def res8():
+        N.check(N.hip.rt_hip_scene_render_rgb8(scene._p, C.byref(cd), 5, buf8.ctypes.data_as(C.POINTER(C.c_uint8)), None), "rt_hip_scene_render_rgb8")
+    res(); res8()
+    tr, _ = best(res, 5)
+    tr8, _ = best(res8, 5)
+    print(f"  rt_hip_scene_render on the resident scene: {tr*1e3:.2f} ms f64, {tr8*1e3:.2f} ms rgb8")
+    scene.close()
     t8, rgb8 = best(lambda: cam.render_rgb8(world))
     print(f"{name} 4096x2160 via rt_hip_render_rgb8 (the same, quantised on the device: 26.5 MB): {t8*1e3:.1f} ms wall, "
           f"{rays/t8/1e6:.0f} Mrays/s PCIe-inclusive")
