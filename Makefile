@@ -26,7 +26,7 @@ HIP_HDR = $(wildcard $(CSRC)/*.h) include/rt_hip.h
 # 2 batch kernels), so that the ~50 large kernels compile in parallel.
 INST_OBJS = $(foreach c,0 1 2,$(foreach s,false true,$(foreach p,0 1,$(OBJDIR)/inst_c$(c)_$(s)_p$(p).o))) \
             $(foreach c,0 1 2,$(OBJDIR)/inst_c$(c)_false_p2.o)
-HIP_OBJS = $(OBJDIR)/rt_hip.o $(OBJDIR)/rt_wf2.o $(OBJDIR)/rt_dirindex.o $(OBJDIR)/rt_hostmem.o $(INST_OBJS)
+HIP_OBJS = $(OBJDIR)/rt_hip.o $(OBJDIR)/rt_wf2.o $(OBJDIR)/rt_dirindex.o $(OBJDIR)/rt_hostmem.o $(OBJDIR)/rt_multi.o $(INST_OBJS)
 
 all: hip host oracle exercise
 
@@ -46,7 +46,7 @@ $(OBJDIR)/%.o: $(CSRC)/%.hip $(HIP_HDR)
 
 $(LIBDIR)/librt_hip.so: $(HIP_OBJS)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $(HIP_OBJS)
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $(HIP_OBJS) -ldl
 
 $(LIBDIR)/librt_host.so: $(HOST_SRC) $(HOST_HDR) $(LIBDIR)/librt_hip.so
 	@mkdir -p $(LIBDIR)

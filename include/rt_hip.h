@@ -269,6 +269,20 @@ void rt_hip_scene_destroy(RtScene* scene);
 int rt_hip_render(const RtSceneDesc* desc, const RtCameraDesc* cam, uint32_t depth, double* out_rgb,
                   RtStats* stats);
 
+/* rt_hip_render with the frame's rows dealt over the first `n_devices` HIP devices of this process (1 <= n_devices <=
+ * the device count): the tables are copied to every device, each traces interleaved 8-row bands of the frame on a
+ * stream and host thread of its own, the shards are gathered to device 0 -- one ncclSend per peer, the ncclRecvs grouped
+ * on device 0 (RCCL, loaded from librccl.so at run time), or hipMemcpyPeerAsync when RCCL cannot be had or
+ * RT_HIP_MULTI_GATHER=peer is set -- and the frame crosses PCIe once, from device 0.  Same pixels as rt_hip_render for
+ * every n_devices (pixels are independent: camera.rs:54-62).  Communicators, streams and buffers are kept until
+ * rt_hip_shutdown; one call at a time per process.  `stats`: counters summed over the devices, kernel_ms of the slowest.
+ * Replaces: `Camera::render` where the reference would use all cores of the machine (rayon: camera.rs:54). */
+int rt_hip_render_multi(const RtSceneDesc* desc, const RtCameraDesc* cam, uint32_t depth, uint32_t n_devices, double* out_rgb,
+                        RtStats* stats);
+/* How rt_hip_render_multi gathers shards in this process: "rccl" (librccl.so and its symbols resolved) or "peer"
+ * (hipMemcpyPeerAsync).  A static string.  Replaces: nothing in the reference. */
+const char* rt_hip_multi_transport(void);
+
 /* `Camera::render(&world)` followed by the per-channel rule of `Canvas::to_ppm` (camera.rs:51-66 +
  * canvas.rs:85-90): the frame is quantised on the device and only the 8-bit samples cross PCIe.
  * out_rgb8[vsize*hsize*3] is a HOST buffer, index = (y*hsize + x)*3 + channel.  `stats` may be NULL. */

@@ -145,7 +145,7 @@ class RthCamera(C.Structure):
 
 # Every symbol include/rt_hip.h declares (checked by tests/test_capi_symbols.py).
 HIP_SYMBOLS = ["rt_hip_init", "rt_hip_shutdown", "rt_hip_strerror", "rt_hip_last_hip_error", "rt_hip_scene_create",
-               "rt_hip_scene_destroy", "rt_hip_scene_kernels", "rt_hip_scene_render", "rt_hip_scene_render_rgb8", "rt_hip_scene_set_wavefront", "rt_hip_scene_status", "rt_hip_render", "rt_hip_render_rgb8", "rt_hip_render_rows", "rt_hip_render_rows_noalloc",
+               "rt_hip_scene_destroy", "rt_hip_scene_kernels", "rt_hip_scene_render", "rt_hip_scene_render_rgb8", "rt_hip_scene_set_wavefront", "rt_hip_scene_status", "rt_hip_render", "rt_hip_render_multi", "rt_hip_multi_transport", "rt_hip_render_rgb8", "rt_hip_render_rows", "rt_hip_render_rows_noalloc",
                "rt_hip_color_at", "rt_hip_shade_rays",
                "rt_hip_probe", "rt_hip_quantize"]
 
@@ -170,6 +170,9 @@ _sig(hip, "rt_hip_scene_status", C.c_int, _vp, _vp)
 _sig(hip, "rt_hip_scene_kernels", C.c_char_p, _vp, C.c_uint32)
 _sig(hip, "rt_hip_render", C.c_int, C.POINTER(RtSceneDesc), C.POINTER(RtCameraDesc), C.c_uint32, c_double_p,
      C.POINTER(RtStats))
+_sig(hip, "rt_hip_render_multi", C.c_int, C.POINTER(RtSceneDesc), C.POINTER(RtCameraDesc), C.c_uint32, C.c_uint32, c_double_p,
+     C.POINTER(RtStats))
+_sig(hip, "rt_hip_multi_transport", C.c_char_p)
 _sig(hip, "rt_hip_render_rgb8", C.c_int, C.POINTER(RtSceneDesc), C.POINTER(RtCameraDesc), C.c_uint32,
      C.POINTER(C.c_uint8), C.POINTER(RtStats))
 _sig(hip, "rt_hip_scene_render", C.c_int, _vp, C.POINTER(RtCameraDesc), C.c_uint32, c_double_p, C.POINTER(RtStats))

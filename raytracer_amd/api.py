@@ -515,6 +515,17 @@ class Camera:
         canvas = Canvas(self.h_size, self.v_size, out)
         return (canvas, st) if stats else canvas
 
+    def render_multi(self, world, n_devices, stats=False):
+        """`render(world)` with the rows dealt over the first n_devices HIP devices of this process (rt_hip_render_multi)."""
+        out = np.empty((self.v_size, self.h_size, 3), dtype=np.float64)
+        flat = world.flatten()
+        cd = self.desc()
+        st = N.RtStats() if stats else None
+        N.check(N.hip.rt_hip_render_multi(flat.desc, C.byref(cd), Camera.DEPTH, n_devices, _dp(out), C.byref(st) if stats else None),
+                "rt_hip_render_multi")
+        canvas = Canvas(self.h_size, self.v_size, out)
+        return (canvas, st) if stats else canvas
+
     def render_rgb8(self, world):
         """`render(world)` + scale_to_ppm_data per channel (canvas.rs:85-90) on the device -> uint8 [v, h, 3]."""
         out = np.empty((self.v_size, self.h_size, 3), dtype=np.uint8)

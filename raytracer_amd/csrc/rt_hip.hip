@@ -543,6 +543,7 @@ int rt_hip_init(int device) {
 }
 
 void rt_hip_shutdown(void) {
+    rth::multi_shutdown();
     rth::hostmem_shutdown();
     std::lock_guard<std::mutex> lock(g_mutex);
     g_initialised = false;

@@ -83,6 +83,9 @@ int block_alloc(void** out, size_t bytes);
 void block_free(void* p);
 int copy_to_host(void* dst, const void* d_src, size_t bytes, hipStream_t producer, hipEvent_t after = nullptr);
 void hostmem_shutdown();
+// rt_multi.hip: what rt_hip_render_multi keeps (communicators, streams, buffers) released; whether librccl.so resolved
+void multi_shutdown();
+int rccl_available();
 // rt_dirindex.hip: the cell table of the direction index built on the current device from the candidates' quadratic
 // forms (blocking; default stream).  res_hint: the resolution the caller's tables were meant for; the library picks
 // its own from the number of candidates (RT_HIP_DIR_RES in the environment overrides).

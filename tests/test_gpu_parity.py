@@ -310,3 +310,41 @@ def test_pipeline_in_batches_of_rows():
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_render_multi_equals_render():
+    """rt_hip_render_multi: n_devices = 1 is rt_hip_render bit for bit (frame and counters); with the test knob that
+    runs several logical devices on the one GPU here (RT_HIP_MULTI_ALIAS=1) the shards, their landing area on device 0
+    and the strided scatter into the frame are exercised for 2, 3 and 8 parts, ragged last band included.  The RCCL
+    gather itself needs as many GPUs as parts and is not run here (librccl.so must resolve, though)."""
+    import subprocess, sys, os
+    code = r'''
+import sys
+import numpy as np
+import raytracer_amd as rt
+for name, w, h in (("cover", 203, 117), ("synthetic", 256, 150)):
+    world, cam = rt.synthetic(w, h, 1500) if name == "synthetic" else rt.exercise(name, w, h)
+    ref, st = cam.render(world, stats=True)
+    one, st1 = cam.render_multi(world, 1, stats=True)
+    assert np.array_equal(one.pixels, ref.pixels), name
+    a, b = st.as_dict(), st1.as_dict()
+    for k in ("rays_primary", "rays_shadow", "rays_reflect", "rays_refract", "hits_shaded", "lightings", "schlicks"):
+        assert a[k] == b[k], (name, k, a[k], b[k])  # (counters of the acceleration structures depend on how waves are cut)
+    for n in (2, 3, 8):
+        got, stn = cam.render_multi(world, n, stats=True)
+        assert np.array_equal(got.pixels, ref.pixels), (name, n)
+        assert stn.rays_primary == st.rays_primary and stn.hits_shaded == st.hits_shaded, (name, n)
+print("ok")
+'''
+    env = dict(os.environ, RT_HIP_MULTI_ALIAS="1", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+    from raytracer_amd import _native as N
+    import ctypes as C
+    world, cam = rt.exercise("plane", 64, 36)
+    out = np.empty((36, 64, 3))
+    cd = cam.desc()
+    flat = world.flatten()
+    rc = N.hip.rt_hip_render_multi(flat.desc, C.byref(cd), 5, 4096, out.ctypes.data_as(C.POINTER(C.c_double)), None)
+    assert rc == N.RT_ERR_INVALID_ARG  # more devices than the machine has
+    assert N.hip.rt_hip_multi_transport() == b"rccl"  # /opt/rocm/lib/librccl.so is part of the image
