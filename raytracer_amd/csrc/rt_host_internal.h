@@ -62,7 +62,7 @@ namespace rth {
 // rt_wf2.hip.  wf2_create leaves *out null (and returns RT_OK) for scenes the pipeline does not cover.
 // Its tables go into the scene's arena; wf2_bind gives it the device address of the block once that exists.
 int wf2_create(const RtSceneDesc& desc, uint32_t scene_flags, Arena& arena, Wf2** out);
-void wf2_bind(Wf2* w, unsigned char* base);
+const rtd::Wf2Accel* wf2_bind(Wf2* w, Arena& arena, unsigned char* base);  // -> the accel record on the device (null: no pipeline)
 void wf2_destroy(Wf2* w);
 // One frame (or row-band shard) through the pipeline, asynchronously on `stream`.  RT_ERR_HIP when the workspace
 // cannot be had: the caller then falls back to the one-launch kernel (same frame).

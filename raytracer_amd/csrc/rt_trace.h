@@ -41,6 +41,7 @@ namespace rtd {
 #define RT_SCENE_NESTED_LEAVES 16u  // the world-level hierarchy names shapes nested in groups directly (global hierarchy)
 #define RT_SCENE_RECURSIVE 4u  // some material reflects or transmits: color_at can recurse (world.rs:98-127)
 
+struct Wf2Accel;  // rt_bvh4.h
 struct SceneDev {
     const RtShape* __restrict__ shapes;
     const RtConic* __restrict__ conics;
@@ -70,6 +71,7 @@ struct SceneDev {
     uint32_t stage_bytes;
     uint32_t stage_off[10];  // shapes conics mats pats lights | scenes with compounds also: groups csgs lhit bvh tris
     uint32_t lds_list_cap;  // staged scenes: the most entries World::intersections can return = per-lane list slots in LDS
+    const Wf2Accel* __restrict__ accel4;  // the 4-wide hierarchy of scenes that have one (rt_bvh4.h), else null
 };
 
 // ---- event counters (RtStats order) ------------------------------------------
@@ -724,6 +726,8 @@ RT_DEV int world_list(const SceneDev& S, SW& W, const Ray& ray, double bound, Ct
     }
 }
 
+#include "rt_bvh4.h"
+
 // One ray against the world.  shadow == false: closest hit into `best` (world.rs:32-36,
 // intersection.rs:154-158).  shadow == true: returns true as soon as a shadow-casting
 // primitive is met at 0 <= t < limit (world.rs:85-96).  Colour rays and shadow feelers share
@@ -760,6 +764,9 @@ RT_DEV bool trace(const SceneDev& S, SW& W, const Ray& world_ray, bool shadow, d
         }
         return found;
     } else {
+    if constexpr (FLAT == RT_CLASS_NESTED_LEAVES) {
+        if (S.accel4) return trace4(S, world_ray, shadow, limit, best, cx);
+    }
     int level = 0;
     int floor = 0;  // level whose exhaustion ends the current source (a direction candidate, or the walk)
     Ray ray = world_ray;

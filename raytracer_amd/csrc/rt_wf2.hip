@@ -14,7 +14,7 @@ using namespace rtd;
 using namespace rtk;
 
 struct Wf2 {
-    size_t off_nodes = 0, off_pre = 0;  // the hierarchy and the leaf records inside the scene's block of tables
+    size_t off_nodes = 0, off_pre = 0, off_accel = 0;  // the hierarchy, the leaf records and the accel record inside the scene's block of tables
     bool has_pre = false;
     Wf2Accel accel{};
     uint32_t n_nodes = 0, stack_need = 0;
@@ -518,6 +518,7 @@ int rth::wf2_create(const RtSceneDesc& d, uint32_t scene_flags, Arena& arena, Wf
         w->off_pre = arena.add(pre.data(), pre.size() * sizeof(LeafPre));
         arena.reserve(sizeof(LeafPre));
     }
+    w->off_accel = arena.reserve(sizeof(Wf2Accel));
     auto body = [&]() -> int {
         // the device's compute units and how many one-wave blocks of each traversal kernel one of them holds: asked once per device
         static std::mutex m;
@@ -562,10 +563,12 @@ void rth::wf2_destroy(Wf2* w) {
     delete w;
 }
 
-void rth::wf2_bind(Wf2* w, unsigned char* base) {
-    if (!w) return;
+const Wf2Accel* rth::wf2_bind(Wf2* w, Arena& arena, unsigned char* base) {
+    if (!w) return nullptr;
     w->accel.nodes = reinterpret_cast<const Bvh4Node*>(base + w->off_nodes);
     w->accel.pre = w->has_pre ? reinterpret_cast<const LeafPre*>(base + w->off_pre) : nullptr;
+    std::memcpy(arena.host.data() + w->off_accel, &w->accel, sizeof(Wf2Accel));  // the copy trace4 reads (rt_bvh4.h)
+    return reinterpret_cast<const Wf2Accel*>(base + w->off_accel);
 }
 
 namespace {

@@ -580,7 +580,7 @@ FlatScene flatten(const World& world, const FlattenOptions& opt) {
     // one group of 9 216 triangles, 1.97 -> 2.09 ms with the global form, which repeats the way down for
     // every leaf) and worlds of plain primitives keep the nested form.
     size_t n_leaves = 0, n_groups = 0;
-    bool nested_groups = false;
+    bool nested_groups = false, has_csg = false;
     {
         std::vector<const Shape*> todo;
         for (const Shape& s : world.shapes()) todo.push_back(&s);
@@ -589,6 +589,7 @@ FlatScene flatten(const World& world, const FlattenOptions& opt) {
             todo.pop_back();
             if (s->is_primitive() || s->compound().kind() == Compound::Kind::Csg) {
                 ++n_leaves;
+                has_csg = has_csg || !s->is_primitive();
                 continue;
             }
             nested_groups = true;
@@ -596,7 +597,10 @@ FlatScene flatten(const World& world, const FlattenOptions& opt) {
             for (const Shape& c : s->compound().children()) todo.push_back(&c);
         }
     }
-    f.global = opt.build_bvh && (opt.hierarchy == 2 || (opt.hierarchy == 0 && nested_groups && n_leaves >= opt.bvh_min_children && n_leaves < 64 * n_groups));
+    // Thousands of primitives and no CSG node: the library walks such a world through its 4-wide hierarchy (rt_bvh4.h),
+    // which is built over the global form (the teapot 1.63 -> 1.31 ms).
+    f.global = opt.build_bvh && (opt.hierarchy == 2 || (opt.hierarchy == 0 && nested_groups && n_leaves >= opt.bvh_min_children &&
+                                                         (n_leaves < 64 * n_groups || (n_leaves >= 2048 && !has_csg))));
     const bool timing = std::getenv("RT_FLATTEN_TIMING") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
