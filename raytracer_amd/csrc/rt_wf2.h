@@ -173,6 +173,12 @@ __global__ __launch_bounds__(256) void wf2_cands_kernel(const SceneDev S, Wf2Spa
 }
 
 // The traversal kernel.  One-wave blocks; every lane holds at most one ray.
+#ifndef RT_WF2_PEND
+#define RT_WF2_PEND 4
+#endif
+#ifndef RT_WF2_PEND_COLOUR
+#define RT_WF2_PEND_COLOUR 0  // the same for colour rays (closest hit): every leaf can shorten the rest of their walk
+#endif
 #ifndef RT_WF2_TRACE_WAVES
 #define RT_WF2_TRACE_WAVES 4  // waves per SIMD the traversal kernel is compiled for (<= 128 VGPRs)
 #endif
@@ -182,8 +188,12 @@ __global__ __launch_bounds__(64, RT_WF2_TRACE_WAVES) void wf2_trace_kernel(const
     constexpr int CLS = RT_CLASS_NESTED_LEAVES;
     constexpr bool SHADOW = MODE == WF2_SHADOW;
     constexpr bool LIST = MODE == WF2_CONTAINERS;  // n1 / n2 of the transparent hits: the sorted world list up to the hit
+    constexpr int PEND = (SHADOW || LIST) ? RT_WF2_PEND : RT_WF2_PEND_COLOUR;  // leaves a lane may set aside while other lanes look for theirs
     __shared__ uint32_t lds_stack_all[RT_WF2_LDS_STACK * 64];
+    __shared__ uint32_t pend_all[(PEND > 0 ? PEND : 1) * 64];
     uint32_t* lds_stack = lds_stack_all + threadIdx.x;
+    uint32_t* pend = pend_all + threadIdx.x;
+    unsigned p_head = 0, p_n = 0;
     uint32_t deep[RT_WF2_MAX_STACK - RT_WF2_LDS_STACK];
     Ctx<STATS, CLS> cx;
     cx.status = 0;
@@ -244,6 +254,7 @@ __global__ __launch_bounds__(64, RT_WF2_TRACE_WAVES) void wf2_trace_kernel(const
                     busy = true;
                     best.t = __builtin_inf(), best.idx = -1;
                     found = false;
+                    p_head = p_n = 0u;
                     bool valid;
                     if constexpr (LIST) {
                         slot = sp.creq[item];
@@ -305,28 +316,56 @@ __global__ __launch_bounds__(64, RT_WF2_TRACE_WAVES) void wf2_trace_kernel(const
             }
         }
         RT_STAMP(0)
+        // ---- box tests only, until every busy lane holds a leaf or is through.  (Measured and rejected: leaving the loop
+        // for the leaves at hand once only 4-48 lanes are still walking -- 30.7 ms at 0 and 4, 31.3-36.4 ms at 8-48.)
+        // Feelers and the containers walk (PEND > 0): a lane that has its leaf does not idle while others still look for
+        // theirs -- it sets the leaf aside (a ring of PEND per lane in LDS, worked off one per round below, in the order
+        // found) and walks on.  Nothing a leaf yields could have shortened those walks much: a feeler that is lit goes
+        // through the whole segment anyway, the containers list is cut at a fixed bound.
+        if constexpr (PEND > 0) {
+            for (;;) {
+                const bool inner = busy && w.cur < RT_BVH4_DONE;
+                if (__builtin_amdgcn_ballot_w64(inner && p_n == 0u) == 0ull) break;
 #ifdef RT_WF2_PROFILE
-        {   // lanes in the walk loop, summed per step, against steps * 64
+                pn[0] += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(inner || (busy && (w.cur & RT_BVH4_LEAF) && p_n < (unsigned)PEND)));
+                pn[1] += 64u;
+#endif
+                if (inner) {
+                    walk_step(A, f, t_near, t_far, w, lds_stack, deep, cx);
+                } else if (busy && (w.cur & RT_BVH4_LEAF) && p_n < (unsigned)PEND) {
+                    pend[((p_head + p_n) % (unsigned)PEND) * 64u] = w.cur;
+                    ++p_n;
+                    walk_pop(w, lds_stack, deep);
+                }
+            }
+        } else {
+#ifdef RT_WF2_PROFILE
             while (__builtin_amdgcn_ballot_w64(busy && w.cur < RT_BVH4_DONE) != 0ull) {
                 pn[0] += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(busy && w.cur < RT_BVH4_DONE));
                 pn[1] += 64u;
                 if (busy && w.cur < RT_BVH4_DONE) walk_step(A, f, t_near, t_far, w, lds_stack, deep, cx);
             }
+#else
+            while (busy && w.cur < RT_BVH4_DONE) walk_step(A, f, t_near, t_far, w, lds_stack, deep, cx);
+#endif
         }
-#endif
-#ifndef RT_WF2_PROFILE
-        // ---- box tests only, until every busy lane holds a leaf or is through.  (Measured and rejected: leaving the loop
-        // for the leaves at hand once only 4-48 lanes are still walking -- 30.7 ms at 0 and 4, 31.3-36.4 ms at 8-48.)
-        while (busy && w.cur < RT_BVH4_DONE) walk_step(A, f, t_near, t_far, w, lds_stack, deep, cx);
-#endif
         RT_STAMP(1)
 #ifdef RT_WF2_PROFILE
         pt[4] += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(busy && (w.cur & RT_BVH4_LEAF)));
         pt[5] += 64u;
 #endif
-        // ---- leaves
-        if (busy && (w.cur & RT_BVH4_LEAF)) {
-            const int s = (int)(w.cur & ~RT_BVH4_LEAF);
+        // ---- leaves: the oldest one set aside, else the one at hand
+        const bool from_ring = PEND > 0 && busy && p_n != 0u;
+        if (from_ring || (busy && (w.cur & RT_BVH4_LEAF))) {
+            uint32_t leaf = w.cur;
+            if constexpr (PEND > 0) {
+                if (from_ring) {
+                    leaf = pend[p_head * 64u];
+                    p_head = (p_head + 1u) % (unsigned)PEND;
+                    --p_n;
+                }
+            }
+            const int s = (int)(leaf & ~RT_BVH4_LEAF);
             bool hit_shadow = false;
             bool worth = true;
             uint32_t anc0 = RT_PRE_DEEP, anc1 = RT_PRE_NO_ANC;
@@ -341,29 +380,24 @@ __global__ __launch_bounds__(64, RT_WF2_TRACE_WAVES) void wf2_trace_kernel(const
                 else
                     hit_shadow = wf2_leaf<SHADOW>(S, s, ray, limit, best, cx, anc0, anc1);
             }
-            if (LIST) {
-                walk_pop(w, lds_stack, deep);
-            } else if (SHADOW) {
-                if (hit_shadow) {
-                    found = true;
-                    w.cur = RT_BVH4_DONE;
-                } else {
-                    walk_pop(w, lds_stack, deep);
-                }
-            } else {
-                t_far = f32_up(best.t);
+            if (SHADOW && hit_shadow) {
+                found = true;
+                w.cur = RT_BVH4_DONE;
+                p_n = 0u;
+            } else if (!from_ring) {
+                if (!LIST && !SHADOW) t_far = f32_up(best.t);
                 walk_pop(w, lds_stack, deep);
             }
         }
         RT_STAMP(2)
         // ---- rays that are through
-        if (LIST && busy && w.cur == RT_BVH4_DONE && second_walk) {
+        if (LIST && busy && w.cur == RT_BVH4_DONE && p_n == 0u && second_walk) {
             second_walk = false;
             t_near = -__builtin_inff();
             w.sp = 1;
             w.cur = A.root_open;
         }
-        if (busy && w.cur == RT_BVH4_DONE) {
+        if (busy && w.cur == RT_BVH4_DONE && p_n == 0u) {
             if constexpr (LIST) {
                 double n1, n2;
                 containers_walk(S, W, top, ctx_f(sp, slot, CX_T), n1, n2, cx);
