@@ -46,12 +46,22 @@ enum { CX_OVER = 0, CX_UNDER = 3, CX_EYE = 6, CX_NORMAL = 9, CX_REFLECT = 12, CX
        CX_T = 21, CX_N1 = 22, CX_N2 = 23, CX_DOUBLES = 24 };
 enum { CU_MAT = 0, CU_PARENT = 1, CU_REMAINING = 2, CU_ITEM = 3, CU_UINTS = 4 };
 
+// Counters many waves bump at once are split RT_WF2_PARTS ways, one 128-byte line each: atomics on ONE address are
+// served one after the other (~11 ns each, measured: a second per-wave atomic doubled wf2_prepare_kernel's time), and a
+// frame has half a million 64-ray chunks to hand out.
+#ifndef RT_WF2_PARTS
+#define RT_WF2_PARTS 32u  // a multiple of the 8 XCDs: block b's home part b % PARTS is then always served by the same L2
+#endif
+struct alignas(128) Wf2Padded {
+    unsigned v;
+    unsigned pad[31];
+};
 struct Wf2Counters {
     unsigned n_rays[RT_WF_LEVELS + 1];  // colour rays of generation g (dense queue length)
-    unsigned n_hits;                    // shading contexts of the generation at hand
-    unsigned n_creq;                    // ... of which transparent: containers requests
+    unsigned n_hits;                    // shading context slots of the generation at hand (= its colour rays: slot i is ray i's)
     unsigned n_overflow;
-    unsigned chunk[3 * (RT_WF_LEVELS + 1)];  // next chunk of each trace launch (generation x {colour, shadow, containers})
+    Wf2Padded n_creq[RT_WF2_PARTS];     // containers requests (transparent hits), per part of the request list
+    Wf2Padded chunk[3 * (RT_WF_LEVELS + 1)][RT_WF2_PARTS];  // next chunk of each trace launch (generation x {colour, shadow, containers}) per part of its items
     unsigned offsets[RT_WF_SHARDS * RT_WF_BINS + 1];  // compaction: start of each (shard, octant) sub-slice in the dense queue
     unsigned long long prof[4][8];  // RT_WF2_PROFILE builds: shader cycles of the traversal kernel by mode and phase, summed over waves
 };
@@ -63,11 +73,14 @@ struct Wf2Space {
     double* ctx_d;     // [CX_DOUBLES][ctx_cap]
     uint32_t* ctx_u;   // [CU_UINTS][ctx_cap]
     uint8_t* occ;      // [n_lights][ctx_cap]: light l is hidden from hit `slot`
-    uint32_t* creq;    // [ctx_cap]
+    uint32_t* creq;    // [RT_WF2_PARTS][creq_part_cap]: slots whose hit is transparent, by part (see wf2_prepare_kernel)
     uint32_t* overflow;  // [ctx_cap]
     Wf2Counters* cnt;
-    unsigned qd_cap, ctx_cap;
+    unsigned qd_cap, ctx_cap, creq_part_cap;
 };
+// slots per part of the request list: a part takes the requests of every RT_WF2_PARTS-th group of four waves
+__host__ __device__ inline unsigned wf2_creq_part_cap(size_t ctx_cap) { return (unsigned)(((ctx_cap + 255u) / 256u + RT_WF2_PARTS - 1u) / RT_WF2_PARTS * 256u); }
+
 
 #ifndef RT_WF2_CHUNK
 #define RT_WF2_CHUNK 64u   // rays a wave takes from the queue at a time (RT_HIP_WF2_CHUNK in the environment: studies)
@@ -121,6 +134,7 @@ RT_DEV bool wf2_item_ray(const SceneDev& S, const Wf2Space& sp, const RtCameraDe
         const double* cd = sp.ctx_d + slot;
         const size_t st = sp.ctx_cap;
         const V3 over = v3(cd[(CX_OVER + 0) * st], cd[(CX_OVER + 1) * st], cd[(CX_OVER + 2) * st]);
+        if (over.x != over.x) return false;  // no hit in this slot (wf2_prepare_kernel's mark)
         const RtLight light = S.lights[l];
         const V3 v = v3(light.position[0], light.position[1], light.position[2]) - over;  // world.rs:86-89
         limit = magnitude(v);
@@ -203,9 +217,14 @@ __global__ __launch_bounds__(64, RT_WF2_TRACE_WAVES) void wf2_trace_kernel(const
     }
     const PixelMap pm = pixel_map(cam, rows);
     const unsigned n_hits = SHADOW ? sp.cnt->n_hits : 0u;
-    const unsigned n = MODE == WF2_PRIMARY ? pm.n_items
-                       : (MODE == WF2_QUEUE ? sp.cnt->n_rays[gen] : (LIST ? sp.cnt->n_creq : n_hits * S.n_lights));
-    unsigned* chunk_counter = &sp.cnt->chunk[3u * gen + (SHADOW ? 1u : (LIST ? 2u : 0u))];
+    // The launch's items in RT_WF2_PARTS parts, each with a counter of its own: equal stretches of the item range, or (LIST)
+    // the parts of the request list.  A wave starts at its block's home part and moves on when a part is used up.
+    const unsigned n = MODE == WF2_PRIMARY ? pm.n_items : (MODE == WF2_QUEUE ? sp.cnt->n_rays[gen] : (LIST ? 0u : n_hits * S.n_lights));
+    Wf2Padded* chunk_counters = sp.cnt->chunk[3u * gen + (SHADOW ? 1u : (LIST ? 2u : 0u))];
+    const unsigned per_part = LIST ? sp.creq_part_cap : ((n + A.chunk - 1u) / A.chunk + RT_WF2_PARTS - 1u) / RT_WF2_PARTS * A.chunk;
+    unsigned part = blockIdx.x % RT_WF2_PARTS, parts_left = RT_WF2_PARTS;
+    unsigned part_lo = part * per_part;
+    unsigned part_hi = LIST ? part_lo + sp.cnt->n_creq[part].v : (part_lo + per_part < n ? part_lo + per_part : n);
     typename std::conditional<LIST, LaneList, int>::type W;
     int top = 0;       // LIST: entries in W
     unsigned slot = 0;  // LIST: the hit's shading context
@@ -235,15 +254,22 @@ __global__ __launch_bounds__(64, RT_WF2_TRACE_WAVES) void wf2_trace_kernel(const
         const unsigned long long idle = __builtin_amdgcn_ballot_w64(!busy);
         const int n_idle = __builtin_popcountll(idle);
         if (n_idle == 64 || (n_idle >= (int)A.refill && !dry)) {
-            if (chunk_next >= chunk_end && !dry) {
-                unsigned c = 0;
-                if (lane == 0) c = atomicAdd(chunk_counter, A.chunk);
-                c = (unsigned)__builtin_amdgcn_readfirstlane((int)c);
-                if (c < n) {
-                    chunk_next = c;
-                    chunk_end = c + A.chunk < n ? c + A.chunk : n;
-                } else {
+            while (chunk_next >= chunk_end && !dry) {
+                unsigned c = 0xffffffffu;
+                if (part_lo < part_hi) {
+                    if (lane == 0) c = atomicAdd(&chunk_counters[part].v, A.chunk);
+                    c = (unsigned)__builtin_amdgcn_readfirstlane((int)c);
+                }
+                if (c < part_hi - part_lo && part_lo < part_hi) {
+                    chunk_next = part_lo + c;
+                    chunk_end = chunk_next + A.chunk < part_hi ? chunk_next + A.chunk : part_hi;
+                } else if (--parts_left == 0u) {
                     dry = true;
+                } else {  // this part is used up: on to the next
+                    part = (part + 1u) % RT_WF2_PARTS;
+                    part_lo = part * per_part;
+                    part_hi = LIST ? part_lo + sp.cnt->n_creq[part].v : (part_lo + per_part < n ? part_lo + per_part : n);
+                    if (!LIST && part_lo > n) part_lo = part_hi = n;
                 }
             }
             const unsigned avail = chunk_end - chunk_next;
@@ -438,10 +464,72 @@ RT_DEV unsigned wave_slots(unsigned* counter, bool want) {
     return base + (unsigned)__builtin_popcountll(asking & ((1ull << lane) - 1ull));
 }
 
+// prepare_computations (intersection.rs:45-99 without n1 / n2) for a leaf nested in at most two groups, as the leaf
+// records name them: the (up to) three inverse matrices are read ONCE and stay in registers for the three passes the
+// reference makes over them (point to object space, normal to world space, over_point to object space), where
+// world_to_object / normal_to_world of rt_trace.h walk the parent links and read every matrix again per pass -- the
+// kernel is bound by its vector memory instructions.  Same operations in the same order.  False: not this leaf
+// (nested deeper, a smooth triangle, no leaf records): the caller uses prepare_computations.
+template <bool STATS, int FLAT>
+RT_DEV bool prepare_in_registers(const SceneDev& S, const LeafPre* __restrict__ pre, const Ray& ray, const Best& hit, Comps& c,
+                                 Ctx<STATS, FLAT>& cx) {
+    if (!pre) return false;
+    const RtShape* __restrict__ sh = S.shapes + hit.idx;
+    const unsigned kind = RT_KIND(sh->kind_flags);
+    const uint2 anc = *reinterpret_cast<const uint2*>(&pre[hit.idx].anc[0]);
+    if (anc.x == RT_PRE_DEEP || kind == RT_SMOOTH_TRIANGLE) return false;
+    const bool has_o = anc.x != RT_PRE_NO_ANC, has_i = anc.y != RT_PRE_NO_ANC;  // outermost group, the one inside it
+    double ms[12], mo[12], mi[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) ms[k] = sh->inv[k], mo[k] = 0.0, mi[k] = 0.0;
+    if (has_o) {
+        const RtShape* __restrict__ g = S.shapes + anc.x;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) mo[k] = g->inv[k];
+    }
+    if (has_i) {
+        const RtShape* __restrict__ g = S.shapes + anc.y;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) mi[k] = g->inv[k];
+    }
+    count(cx, ST_HITS_SHADED);
+    count(cx, ST_NORMAL_LEVELS, 2u * (1u + (has_o ? 1u : 0u) + (has_i ? 1u : 0u)));
+    auto to_object = [&](V3 p) {  // primitive.rs:179-185: trail.iter().rev(), then the primitive itself
+        if (has_o) p = mul_point(mo, p);
+        if (has_i) p = mul_point(mi, p);
+        return mul_point(ms, p);
+    };
+    const V3 point = ray.o + ray.d * hit.t;  // ray.rs:15-17
+    c.idx = hit.idx;
+    c.t = hit.t;
+    c.eye_v = -ray.d;
+    const V3 local_point = to_object(point);
+    const V3 local_n = local_normal(S, sh, kind, local_point, nullptr, 0, ray);  // (chain and ray: smooth triangles only)
+    V3 normal_v = normalize(mul_vector_transposed(ms, local_n));  // primitive.rs:187-192, inside out
+    if (has_i) normal_v = normalize(mul_vector_transposed(mi, normal_v));
+    if (has_o) normal_v = normalize(mul_vector_transposed(mo, normal_v));
+    c.inside = dot(normal_v, c.eye_v) < 0.0;
+    if (c.inside) normal_v = -normal_v;
+    c.normal_v = normal_v;
+    c.over_point = point + normal_v * EPSILON;
+    c.under_point = point - normal_v * EPSILON;
+    c.reflect_v = reflect(ray.d, normal_v);
+    c.object_over_point = to_object(c.over_point);
+    c.n1 = 1.0;
+    c.n2 = 1.0;
+    return true;
+}
+
 // prepare_computations + pattern colour of every hit of the generation (world.rs:32-43 up to shade_hit's first
 // line); a miss is BLACK, delivered at once (world.rs:41).  PRIMARY: generation 0, items are pixels.
+#ifndef RT_WF2_PREP_WAVES
+#define RT_WF2_PREP_WAVES 1
+#endif
+#ifndef RT_WF2_FINISH_WAVES
+#define RT_WF2_FINISH_WAVES 1
+#endif
 template <bool STATS, bool PRIMARY>
-__global__ __launch_bounds__(256) void wf2_prepare_kernel(const SceneDev S, Wf2Space sp, RtCameraDesc cam, RowMap rows, int depth,
+__global__ __launch_bounds__(256, RT_WF2_PREP_WAVES) void wf2_prepare_kernel(const SceneDev S, const LeafPre* __restrict__ pre, Wf2Space sp, RtCameraDesc cam, RowMap rows, int depth,
                                                           unsigned gen, double* __restrict__ out, RtStats* __restrict__ stats,
                                                           unsigned* __restrict__ status) {
     constexpr int CLS = RT_CLASS_NESTED_LEAVES;
@@ -481,15 +569,24 @@ __global__ __launch_bounds__(256) void wf2_prepare_kernel(const SceneDev S, Wf2S
         }
         const bool has = valid && hit.idx >= 0;
         if (valid && !has) wf_deliver(sp.ws.nodes, out, parent, v3(0.0, 0.0, 0.0));
-        const unsigned slot = wave_slots(&sp.cnt->n_hits, has);
+        // The shading context of ray i is slot i: nine rays in ten hit something, so packing the hits would save little,
+        // and the one counter every wave would bump for its slots was this kernel's whole time (see Wf2Counters).  A slot
+        // without a hit is marked (NaN in over_point.x, no material) and skipped by whoever reads slots.
+        const unsigned slot = i;
+        if (i < n && !has) {
+            ctx_f(sp, slot, CX_OVER) = __builtin_nan("");
+            ctx_u(sp, slot, CU_MAT) = 0xffffffffu;
+        }
         bool want_n = false;
         if (has) {
             const RtShape* __restrict__ sh = S.shapes + hit.idx;
             const RtMaterial m = S.mats[sh->material];
             want_n = m.transparency != 0.0 && remaining != 0u;
-            Scratch unused_list;  // prepare_computations touches the list only for n1 / n2, which come later (dead here)
             Comps c;
-            prepare_computations(S, unused_list, ray, hit, false, c, cx);
+            if (!prepare_in_registers(S, pre, ray, hit, c, cx)) {
+                Scratch unused_list;  // prepare_computations touches the list only for n1 / n2, which come later (dead here)
+                prepare_computations(S, unused_list, ray, hit, false, c, cx);
+            }
             V3 color = v3(m.color[0], m.color[1], m.color[2]);
             if (m.pattern >= 0) {
                 unsigned nodes = 0;
@@ -510,9 +607,12 @@ __global__ __launch_bounds__(256) void wf2_prepare_kernel(const SceneDev S, Wf2S
             ctx_u(sp, slot, CU_REMAINING) = remaining;
             ctx_u(sp, slot, CU_ITEM) = i;
         }
-        const unsigned r = wave_slots(&sp.cnt->n_creq, want_n);
-        if (want_n) sp.creq[r] = slot;
+        // requests for n1 / n2 go to the part of the list that belongs to this group of four waves
+        const unsigned creq_part = (i >> 8) % RT_WF2_PARTS;
+        const unsigned r = wave_slots(&sp.cnt->n_creq[creq_part].v, want_n);
+        if (want_n) sp.creq[(size_t)creq_part * sp.creq_part_cap + r] = slot;
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0) sp.cnt->n_hits = n;
     flush_stats(cx, stats, status);
 }
 
@@ -585,7 +685,7 @@ RT_DEV bool wf2_commit(const WfSpace& ws, unsigned shard, unsigned level, bool w
 // feelers' answers, then the children -- into the node pool and the next generation's queue (wf_commit), or, for a
 // hit that has none, the colour straight to whoever waits for it.
 template <bool STATS>
-__global__ __launch_bounds__(256) void wf2_finish_kernel(const SceneDev S, Wf2Space sp, unsigned gen, unsigned stretch_shift,
+__global__ __launch_bounds__(256, RT_WF2_FINISH_WAVES) void wf2_finish_kernel(const SceneDev S, Wf2Space sp, unsigned gen, unsigned stretch_shift,
                                                          double* __restrict__ out, RtStats* __restrict__ stats,
                                                          unsigned* __restrict__ status) {
     constexpr int CLS = RT_CLASS_NESTED_LEAVES;
@@ -598,7 +698,7 @@ __global__ __launch_bounds__(256) void wf2_finish_kernel(const SceneDev S, Wf2Sp
     const unsigned n = sp.cnt->n_hits;
     const unsigned n_round = (n + 63u) & ~63u;
     for (unsigned slot = blockIdx.x * blockDim.x + threadIdx.x; slot < n_round; slot += gridDim.x * blockDim.x) {
-        const bool active = slot < n;
+        const bool active = slot < n && ctx_u(sp, slot < n ? slot : 0u, CU_MAT) != 0xffffffffu;
         Shade sd;
         sd.surface = v3(0.0, 0.0, 0.0);
         sd.over = sd.reflect_v = v3(0.0, 0.0, 0.0);
@@ -700,8 +800,9 @@ __global__ __launch_bounds__(RT_WF_SHARDS) void wf2_scan_kernel(Wf2Space sp, uns
         }
         sp.cnt->offsets[RT_WF_SHARDS] = run;
         sp.cnt->n_rays[gen + 1u] = run;
-        sp.cnt->n_hits = 0u, sp.cnt->n_creq = 0u, sp.cnt->n_overflow = 0u;
+        sp.cnt->n_hits = 0u, sp.cnt->n_overflow = 0u;
     }
+    if (s < RT_WF2_PARTS) sp.cnt->n_creq[s].v = 0u;
 }
 // One block per shard: the shard's slice into the dense queue, sorted by the octant of the ray's direction (rays that
 // start near each other -- one shard = a few 512-hit stretches of the parent generation -- and point the same way walk

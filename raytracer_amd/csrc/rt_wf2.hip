@@ -317,7 +317,8 @@ Plan plan_for(size_t items, size_t q_items, size_t node_items, uint32_t n_lights
     p.qd_cap = p.q_cap * RT_WF_SHARDS;
     p.ctx_cap = std::max(items, p.qd_cap);
     p.bytes = 2 * p.qd_cap * sizeof(WfItem) + p.node_cap * RT_WF_SHARDS * sizeof(WfNode) + p.ctx_cap * sizeof(Wf2Hit) +
-              p.ctx_cap * (CX_DOUBLES * sizeof(double) + CU_UINTS * sizeof(uint32_t) + 2 * sizeof(uint32_t) + n_lights);
+              p.ctx_cap * (CX_DOUBLES * sizeof(double) + CU_UINTS * sizeof(uint32_t) + 2 * sizeof(uint32_t) + n_lights) +
+              (size_t)RT_WF2_PARTS * 256u * sizeof(uint32_t) + sizeof(Wf2Counters) + 16u * 256u;
     return p;
 }
 
@@ -341,11 +342,12 @@ bool carve_space(Wf2Space& s, unsigned char* base, size_t bytes, const Plan& p, 
     take(&s.ctx_d, p.ctx_cap * CX_DOUBLES * sizeof(double));
     take(&s.ctx_u, p.ctx_cap * CU_UINTS * sizeof(uint32_t));
     take(&s.occ, p.ctx_cap * (n_lights ? n_lights : 1u));
-    take(&s.creq, p.ctx_cap * sizeof(uint32_t));
+    take(&s.creq, (size_t)RT_WF2_PARTS * wf2_creq_part_cap(p.ctx_cap) * sizeof(uint32_t));
     take(&s.overflow, p.ctx_cap * sizeof(uint32_t));
     take(&s.cnt, sizeof(Wf2Counters));
     s.ws.q_cap = (unsigned)p.q_cap, s.ws.node_cap = (unsigned)p.node_cap;
     s.qd_cap = (unsigned)p.qd_cap, s.ctx_cap = (unsigned)p.ctx_cap;
+    s.creq_part_cap = wf2_creq_part_cap(p.ctx_cap);
     return ok;
 }
 
@@ -389,7 +391,7 @@ int ensure_space(Wf2* w, size_t items, size_t q_items, size_t node_items, uint32
     get(&s.ctx_d, p.ctx_cap * CX_DOUBLES * sizeof(double));
     get(&s.ctx_u, p.ctx_cap * CU_UINTS * sizeof(uint32_t));
     get(&s.occ, p.ctx_cap * (n_lights ? n_lights : 1u));
-    get(&s.creq, p.ctx_cap * sizeof(uint32_t));
+    get(&s.creq, (size_t)RT_WF2_PARTS * wf2_creq_part_cap(p.ctx_cap) * sizeof(uint32_t));
     get(&s.overflow, p.ctx_cap * sizeof(uint32_t));
     get(&s.cnt, sizeof(Wf2Counters));
     if (rc != RT_OK) {
@@ -400,6 +402,7 @@ int ensure_space(Wf2* w, size_t items, size_t q_items, size_t node_items, uint32
     s.ws.cam = nullptr;
     s.ws.q_cap = (unsigned)p.q_cap, s.ws.node_cap = (unsigned)p.node_cap;
     s.qd_cap = (unsigned)p.qd_cap, s.ctx_cap = (unsigned)p.ctx_cap;
+    s.creq_part_cap = wf2_creq_part_cap(p.ctx_cap);
     w->batch_pixels = items, w->q_items = q_items, w->node_items = node_items;
     return RT_OK;
 }
@@ -598,11 +601,11 @@ int run_pipeline(const RtScene* scene, const Wf2* w, const Wf2Space& sp, size_t 
                 if (g == 0) {
                     if (A.has_cands) hipLaunchKernelGGL((wf2_cands_kernel<ST, WF2_PRIMARY>), wide, threads, 0, stream, S, sp, *cam, rows, g, d_stats, status);
                     hipLaunchKernelGGL((wf2_trace_kernel<ST, WF2_PRIMARY>), tgrid[0], dim3(64), 0, stream, S, A, sp, *cam, rows, g, d_stats, status);
-                    hipLaunchKernelGGL((wf2_prepare_kernel<ST, true>), wide, threads, 0, stream, S, sp, *cam, rows, (int)depth, g, d_out, d_stats, status);
+                    hipLaunchKernelGGL((wf2_prepare_kernel<ST, true>), wide, threads, 0, stream, S, A.pre, sp, *cam, rows, (int)depth, g, d_out, d_stats, status);
                 } else {
                     if (A.has_cands) hipLaunchKernelGGL((wf2_cands_kernel<ST, WF2_QUEUE>), wide, threads, 0, stream, S, sp, *cam, rows, g, d_stats, status);
                     hipLaunchKernelGGL((wf2_trace_kernel<ST, WF2_QUEUE>), tgrid[1], dim3(64), 0, stream, S, A, sp, *cam, rows, g, d_stats, status);
-                    hipLaunchKernelGGL((wf2_prepare_kernel<ST, false>), wide, threads, 0, stream, S, sp, *cam, rows, (int)depth, g, d_out, d_stats, status);
+                    hipLaunchKernelGGL((wf2_prepare_kernel<ST, false>), wide, threads, 0, stream, S, A.pre, sp, *cam, rows, (int)depth, g, d_out, d_stats, status);
                 }
                 if (A.has_cands) hipLaunchKernelGGL((wf2_cands_kernel<ST, WF2_SHADOW>), wide, threads, 0, stream, S, sp, *cam, rows, g, d_stats, status);
                 hipLaunchKernelGGL((wf2_trace_kernel<ST, WF2_SHADOW>), tgrid[2], dim3(64), 0, stream, S, A, sp, *cam, rows, g, d_stats, status);
