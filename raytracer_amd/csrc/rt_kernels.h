@@ -81,6 +81,7 @@ __global__ __launch_bounds__(256, DENSE ? (RECURSE ? 3 : RT_WAVES_PER_SIMD_DENSE
                                                      unsigned* __restrict__ status) {
     SceneDev S = S_in;
     if constexpr (STAGED) {
+        S.accel4 = nullptr;  // staged scenes walk the skip-link nodes in their LDS copy (a constant here: trace4 and its LDS stack drop out)
         const uint4* __restrict__ src = reinterpret_cast<const uint4*>(S_in.stage);
         uint4* dst = reinterpret_cast<uint4*>(rt_lds);
         for (unsigned i = threadIdx.x; i < S_in.stage_bytes / 16u; i += blockDim.x) dst[i] = src[i];
@@ -150,6 +151,7 @@ __global__ __launch_bounds__(256, FLAT == RT_CLASS_FLAT ? RT_WAVES_PER_SIMD_FLAT
     unsigned* __restrict__ status, WfSpace ws, unsigned level) {
     SceneDev S = S_in;
     if constexpr (STAGED) {
+        S.accel4 = nullptr;  // staged scenes walk the skip-link nodes in their LDS copy (a constant here: trace4 and its LDS stack drop out)
         const uint4* __restrict__ src = reinterpret_cast<const uint4*>(S_in.stage);
         uint4* dst = reinterpret_cast<uint4*>(rt_lds);
         for (unsigned i = threadIdx.x; i < S_in.stage_bytes / 16u; i += blockDim.x) dst[i] = src[i];
