@@ -371,8 +371,25 @@ int ensure_wavefront_space(const RtScene* scene, size_t pixels) {
         scene->wf_pixels = 0;
     }
     // capacities are per shard; at least one wave's worth each, so that a tiny frame is not all refusals
-    const size_t q_items = scene->wf_q_items ? scene->wf_q_items : pixels * RT_WF_QUEUE_PER_PIXEL;
-    const size_t node_items = scene->wf_node_items ? scene->wf_node_items : pixels * RT_WF_NODES_PER_PIXEL;
+    // Default capacities: 640 B per pixel, but never more than a fixed budget (24 GB, or half of the free device memory:
+    // RT_HIP_WF_BUDGET_MB as for the kernel pipeline) -- a larger frame gets proportionally smaller queues and pool, and the
+    // hits that find no room keep their subtrees to themselves (slower, same frame).
+    size_t q_default = pixels * RT_WF_QUEUE_PER_PIXEL, node_default = pixels * RT_WF_NODES_PER_PIXEL;
+    {
+        const char* e = std::getenv("RT_HIP_WF_BUDGET_MB");
+        const long mb = e && *e ? std::atol(e) : 0;
+        size_t budget = (size_t)(mb > 0 ? mb : 24576) << 20;
+        size_t free_b = 0, total_b = 0;
+        if (mb <= 0 && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b / 2 < budget) budget = free_b / 2;
+        const size_t want = 2 * q_default * sizeof(WfItem) + node_default * sizeof(WfNode);
+        if (want > budget && want > 0) {
+            const double scale = (double)budget / (double)want;
+            q_default = (size_t)((double)q_default * scale);
+            node_default = (size_t)((double)node_default * scale);
+        }
+    }
+    const size_t q_items = scene->wf_q_items ? scene->wf_q_items : q_default;
+    const size_t node_items = scene->wf_node_items ? scene->wf_node_items : node_default;
     size_t q_cap = (q_items + RT_WF_SHARDS - 1) / RT_WF_SHARDS, node_cap = (node_items + RT_WF_SHARDS - 1) / RT_WF_SHARDS;
     if (!scene->wf_q_items && q_cap < 128) q_cap = 128;
     if (!scene->wf_node_items && node_cap < 64) node_cap = 64;

@@ -187,6 +187,9 @@ __global__ __launch_bounds__(256) void wf2_cands_kernel(const SceneDev S, Wf2Spa
 }
 
 // The traversal kernel.  One-wave blocks; every lane holds at most one ray.
+#ifndef RT_WF2_CANDS_INLINE
+#define RT_WF2_CANDS_INLINE 1  // the traversal kernel evaluates the direction candidates when it takes a ray (a whole wave refills at once); 0: wf2_cands_kernel ahead of every trace launch, 21.8 ms against 21.4
+#endif
 #ifndef RT_WF2_PEND
 #define RT_WF2_PEND 4
 #endif
@@ -304,7 +307,11 @@ __global__ __launch_bounds__(64, RT_WF2_TRACE_WAVES) void wf2_trace_kernel(const
                         }
                     } else {
                         valid = wf2_item_ray<MODE>(S, sp, cam, rows, pm, item, n_hits, ray, limit);
-                        if (A.has_cands) {  // what the direction index already found for this ray
+#if RT_WF2_CANDS_INLINE
+                        // the direction index's candidates first (a whole wave refills at once: the lanes are together here)
+                        if (A.has_cands && valid) found = wf2_candidates<SHADOW>(S, ray, limit, best, cx);
+#else
+                        if (A.has_cands) {  // what the direction index already found for this ray (wf2_cands_kernel)
                             if constexpr (SHADOW) {
                                 found = sp.occ[item] != 0;
                             } else {
@@ -312,6 +319,7 @@ __global__ __launch_bounds__(64, RT_WF2_TRACE_WAVES) void wf2_trace_kernel(const
                                 best.t = h0.t, best.idx = h0.idx;
                             }
                         }
+#endif
                     }
                     ray_f32(ray, A.extent, A.slack, f);
                     t_far = (SHADOW || LIST) ? f32_up(limit) : f32_up(best.t);

@@ -581,6 +581,7 @@ int run_pipeline(const RtScene* scene, const Wf2* w, const Wf2Space& sp, size_t 
                  const RowMap& rows_in, double* d_out, hipStream_t stream, RtStats* d_stats) {
     const SceneDev& S = scene->dev;
     const Wf2Accel A = w->accel;
+    const bool cands_pass = A.has_cands && !RT_WF2_CANDS_INLINE;  // the direction candidates in a kernel of their own
     unsigned* status = scene->d_status;
     const dim3 wide(2048), threads(256);
     auto go = [&](auto stats_tag) {
@@ -599,15 +600,15 @@ int run_pipeline(const RtScene* scene, const Wf2* w, const Wf2Space& sp, size_t 
             (void)hipMemsetAsync(sp.cnt, 0, sizeof(Wf2Counters), stream);
             for (unsigned g = 0; g <= depth; ++g) {
                 if (g == 0) {
-                    if (A.has_cands) hipLaunchKernelGGL((wf2_cands_kernel<ST, WF2_PRIMARY>), wide, threads, 0, stream, S, sp, *cam, rows, g, d_stats, status);
+                    if (cands_pass) hipLaunchKernelGGL((wf2_cands_kernel<ST, WF2_PRIMARY>), wide, threads, 0, stream, S, sp, *cam, rows, g, d_stats, status);
                     hipLaunchKernelGGL((wf2_trace_kernel<ST, WF2_PRIMARY>), tgrid[0], dim3(64), 0, stream, S, A, sp, *cam, rows, g, d_stats, status);
                     hipLaunchKernelGGL((wf2_prepare_kernel<ST, true>), wide, threads, 0, stream, S, A.pre, sp, *cam, rows, (int)depth, g, d_out, d_stats, status);
                 } else {
-                    if (A.has_cands) hipLaunchKernelGGL((wf2_cands_kernel<ST, WF2_QUEUE>), wide, threads, 0, stream, S, sp, *cam, rows, g, d_stats, status);
+                    if (cands_pass) hipLaunchKernelGGL((wf2_cands_kernel<ST, WF2_QUEUE>), wide, threads, 0, stream, S, sp, *cam, rows, g, d_stats, status);
                     hipLaunchKernelGGL((wf2_trace_kernel<ST, WF2_QUEUE>), tgrid[1], dim3(64), 0, stream, S, A, sp, *cam, rows, g, d_stats, status);
                     hipLaunchKernelGGL((wf2_prepare_kernel<ST, false>), wide, threads, 0, stream, S, A.pre, sp, *cam, rows, (int)depth, g, d_out, d_stats, status);
                 }
-                if (A.has_cands) hipLaunchKernelGGL((wf2_cands_kernel<ST, WF2_SHADOW>), wide, threads, 0, stream, S, sp, *cam, rows, g, d_stats, status);
+                if (cands_pass) hipLaunchKernelGGL((wf2_cands_kernel<ST, WF2_SHADOW>), wide, threads, 0, stream, S, sp, *cam, rows, g, d_stats, status);
                 hipLaunchKernelGGL((wf2_trace_kernel<ST, WF2_SHADOW>), tgrid[2], dim3(64), 0, stream, S, A, sp, *cam, rows, g, d_stats, status);
                 const bool more = g < depth && (S.flags & RT_SCENE_RECURSIVE);  // only hits with recursion budget left can have children
                 if (more)
@@ -722,6 +723,6 @@ int rth::wf2_render_noalloc(const RtScene* scene, const RtCameraDesc* cam, uint3
 }
 
 const char* rth::wf2_describe() {
-    return "kernel pipeline per generation of rays: wf2_trace_kernel (4-wide f32 hierarchy, persistent waves) for colour rays and "
-           "shadow feelers + wf2_cands / wf2_prepare / wf2_finish / wf2_overflow / wf2_compact + wf_combine_kernel";
+    return "kernel pipeline per generation of rays: wf2_trace_kernel (4-wide f32 hierarchy, persistent waves) for colour rays, "
+           "shadow feelers and containers walks + wf2_prepare / wf2_finish / wf2_overflow / wf2_compact + wf_combine_kernel";
 }
