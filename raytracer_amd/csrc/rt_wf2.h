@@ -812,22 +812,43 @@ __global__ __launch_bounds__(RT_WF_SHARDS) void wf2_scan_kernel(Wf2Space sp, uns
     }
     if (s < RT_WF2_PARTS) sp.cnt->n_creq[s].v = 0u;
 }
-// One block per shard: the shard's slice into the dense queue, sorted by the octant of the ray's direction (rays that
-// start near each other -- one shard = a few 512-hit stretches of the parent generation -- and point the same way walk
-// the same part of the hierarchy).
-__global__ __launch_bounds__(256) void wf2_compact_kernel(Wf2Space sp, unsigned gen) {
-    __shared__ unsigned count[RT_WF_BINS], start[RT_WF_BINS];
+// One block per shard: the shard's slice into the dense queue, counting-sorted by where the ray starts (a grid of
+// RT_WF2_SORT_CELLS^3 cells over the scene's extent, in Morton order) and the octant of its direction: rays that start near
+// each other and point the same way walk the same part of the hierarchy, and 64 neighbours of the dense queue are one wave.
+#ifndef RT_WF2_SORT_CELLS
+#define RT_WF2_SORT_CELLS 4u  // cells per axis (a power of two); 1: by octant only.  Measured 1 / 2 / 4 / 8: 21.3 / 21.0 / 20.85 / 20.84 ms; octant-major keys 21.0; one sort over all slices instead of one per slice 20.95
+#endif
+RT_DEV unsigned wf2_sort_key(const WfItem& it, float ex, float ey, float ez) {
+    unsigned key = wf_octant(it.ray.d);
+    if constexpr (RT_WF2_SORT_CELLS > 1u) {
+        const float n = (float)RT_WF2_SORT_CELLS;
+        auto cell = [n](double o, float e) {
+            const float u = ((float)o / e + 1.f) * 0.5f * n;
+            return (unsigned)(u > 0.f ? (u < n ? u : n - 1.f) : 0.f);  // (NaN -> 0)
+        };
+        const unsigned cx = cell(it.ray.o.x, ex), cy = cell(it.ray.o.y, ey), cz = cell(it.ray.o.z, ez);
+        unsigned morton = 0;
+#pragma unroll
+        for (unsigned b = 0; (1u << b) < RT_WF2_SORT_CELLS; ++b)
+            morton |= (((cx >> b) & 1u) << (3u * b)) | (((cy >> b) & 1u) << (3u * b + 1u)) | (((cz >> b) & 1u) << (3u * b + 2u));
+        key = morton * RT_WF_BINS + key;
+    }
+    return key;
+}
+__global__ __launch_bounds__(256) void wf2_compact_kernel(Wf2Space sp, unsigned gen, float ex, float ey, float ez) {
+    constexpr unsigned KEYS = RT_WF_BINS * RT_WF2_SORT_CELLS * RT_WF2_SORT_CELLS * RT_WF2_SORT_CELLS;
+    __shared__ unsigned count[KEYS], start[KEYS];
     const unsigned shard = blockIdx.x;
     const unsigned begin = sp.cnt->offsets[shard], n = sp.cnt->offsets[shard + 1u] - begin;
     const WfItem* __restrict__ src = sp.ws.queue[(gen + 1u) & 1u] + (size_t)shard * sp.ws.q_cap;
     WfItem* __restrict__ dst = sp.qd + begin;
-    if (threadIdx.x < RT_WF_BINS) count[threadIdx.x] = 0u;
+    for (unsigned k = threadIdx.x; k < KEYS; k += 256u) count[k] = 0u;
     __syncthreads();
-    for (unsigned i = threadIdx.x; i < n; i += 256u) atomicAdd(&count[wf_octant(src[i].ray.d)], 1u);
+    for (unsigned i = threadIdx.x; i < n; i += 256u) atomicAdd(&count[wf2_sort_key(src[i], ex, ey, ez)], 1u);
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned run = 0;
-        for (unsigned o = 0; o < RT_WF_BINS; ++o) {
+        for (unsigned o = 0; o < KEYS; ++o) {
             start[o] = run;
             run += count[o];
         }
@@ -835,7 +856,7 @@ __global__ __launch_bounds__(256) void wf2_compact_kernel(Wf2Space sp, unsigned 
     __syncthreads();
     for (unsigned i = threadIdx.x; i < n; i += 256u) {
         const WfItem it = src[i];
-        dst[atomicAdd(&start[wf_octant(it.ray.d)], 1u)] = it;
+        dst[atomicAdd(&start[wf2_sort_key(it, ex, ey, ez)], 1u)] = it;
     }
 }
 

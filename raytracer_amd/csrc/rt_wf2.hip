@@ -617,7 +617,7 @@ int run_pipeline(const RtScene* scene, const Wf2* w, const Wf2Space& sp, size_t 
                 if (!more) break;
                 hipLaunchKernelGGL((wf2_overflow_kernel<ST>), dim3(4096), dim3(64), 0, stream, S, sp, d_out, d_stats, status);
                 hipLaunchKernelGGL(wf2_scan_kernel, dim3(1), dim3(RT_WF_SHARDS), 0, stream, sp, g);
-                hipLaunchKernelGGL(wf2_compact_kernel, dim3(RT_WF_SHARDS), threads, 0, stream, sp, g);
+                hipLaunchKernelGGL(wf2_compact_kernel, dim3(RT_WF_SHARDS), threads, 0, stream, sp, g, A.extent[0], A.extent[1], A.extent[2]);
             }
             if (S.flags & RT_SCENE_RECURSIVE)
                 for (unsigned k = depth; k-- > 0;) rth::launch_combine(sp.ws, k, d_out, stream);
