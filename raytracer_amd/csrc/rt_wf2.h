@@ -190,6 +190,9 @@ __global__ __launch_bounds__(256) void wf2_cands_kernel(const SceneDev S, Wf2Spa
 #ifndef RT_WF2_CANDS_INLINE
 #define RT_WF2_CANDS_INLINE 1  // the traversal kernel evaluates the direction candidates when it takes a ray (a whole wave refills at once); 0: wf2_cands_kernel ahead of every trace launch, 21.8 ms against 21.4
 #endif
+#ifndef RT_WF2_SHADOW_HINT
+#define RT_WF2_SHADOW_HINT 0  // measured: 21.3 ms with, 21.0 without (most feelers of this scene reach their light; the extra test is paid by all)
+#endif
 #ifndef RT_WF2_PEND
 #define RT_WF2_PEND 4
 #endif
@@ -388,39 +391,61 @@ __global__ __launch_bounds__(64, RT_WF2_TRACE_WAVES) void wf2_trace_kernel(const
         pt[4] += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(busy && (w.cur & RT_BVH4_LEAF)));
         pt[5] += 64u;
 #endif
-        // ---- leaves: the oldest one set aside, else the one at hand
-        const bool from_ring = PEND > 0 && busy && p_n != 0u;
-        if (from_ring || (busy && (w.cur & RT_BVH4_LEAF))) {
-            uint32_t leaf = w.cur;
-            if constexpr (PEND > 0) {
-                if (from_ring) {
-                    leaf = pend[p_head * 64u];
-                    p_head = (p_head + 1u) % (unsigned)PEND;
-                    --p_n;
+        // ---- leaves: the oldest one set aside, else the one at hand.  Feelers (RT_WF2_SHADOW_HINT): a wave's feelers go to one
+        // light from neighbouring hits, so the primitive that has just hidden the light from one of them is tried by all the
+        // others at once, in a second pass of the same code -- any occluder will do (world.rs:85-96 asks only whether).
+        int hint = -1;
+#pragma nounroll
+        for (int pass = 0; pass < (SHADOW && RT_WF2_SHADOW_HINT ? 2 : 1); ++pass) {
+            bool take, keep_walk;
+            uint32_t leaf;
+            if (pass == 0) {
+                const bool from_ring = PEND > 0 && busy && p_n != 0u;
+                take = from_ring || (busy && (w.cur & RT_BVH4_LEAF));
+                keep_walk = from_ring;
+                leaf = w.cur;
+                if constexpr (PEND > 0) {
+                    if (from_ring) {
+                        leaf = pend[p_head * 64u];
+                        p_head = (p_head + 1u) % (unsigned)PEND;
+                        --p_n;
+                    }
                 }
+            } else {
+                if (hint < 0) break;  // (the same in every lane)
+                take = busy && !found;
+                keep_walk = true;
+                leaf = RT_BVH4_LEAF | (uint32_t)hint;
             }
             const int s = (int)(leaf & ~RT_BVH4_LEAF);
             bool hit_shadow = false;
-            bool worth = true;
-            uint32_t anc0 = RT_PRE_DEEP, anc1 = RT_PRE_NO_ANC;
-            if (A.pre) {
-                const float reach = fmaxf(fmaxf(fabsf((float)ray.o.x), fabsf((float)ray.o.y)), fabsf((float)ray.o.z)) * 1.000001f + A.extent_max;
-                worth = leaf_may_hit(A.pre + s, ray, reach, anc0, anc1);
-                count(cx, ST_BVH_BOX);  // one more acceleration-only test
+            if (take) {
+                bool worth = true;
+                uint32_t anc0 = RT_PRE_DEEP, anc1 = RT_PRE_NO_ANC;
+                if (A.pre) {
+                    const float reach = fmaxf(fmaxf(fabsf((float)ray.o.x), fabsf((float)ray.o.y)), fabsf((float)ray.o.z)) * 1.000001f + A.extent_max;
+                    worth = leaf_may_hit(A.pre + s, ray, reach, anc0, anc1);
+                    count(cx, ST_BVH_BOX);  // one more acceleration-only test
+                }
+                if (worth) {
+                    if constexpr (LIST)
+                        top = wf2_leaf_list(S, W, top, s, ray, limit, cx, anc0, anc1);
+                    else
+                        hit_shadow = wf2_leaf<SHADOW>(S, s, ray, limit, best, cx, anc0, anc1);
+                }
+                if (SHADOW && hit_shadow) {
+                    found = true;
+                    w.cur = RT_BVH4_DONE;
+                    p_n = 0u;
+                } else if (!keep_walk) {
+                    if (!LIST && !SHADOW) t_far = f32_up(best.t);
+                    walk_pop(w, lds_stack, deep);
+                }
             }
-            if (worth) {
-                if constexpr (LIST)
-                    top = wf2_leaf_list(S, W, top, s, ray, limit, cx, anc0, anc1);
-                else
-                    hit_shadow = wf2_leaf<SHADOW>(S, s, ray, limit, best, cx, anc0, anc1);
-            }
-            if (SHADOW && hit_shadow) {
-                found = true;
-                w.cur = RT_BVH4_DONE;
-                p_n = 0u;
-            } else if (!from_ring) {
-                if (!LIST && !SHADOW) t_far = f32_up(best.t);
-                walk_pop(w, lds_stack, deep);
+            if (SHADOW && RT_WF2_SHADOW_HINT && pass == 0) {
+                const unsigned long long hitters = __builtin_amdgcn_ballot_w64(take && hit_shadow);
+                if (hitters != 0ull && __builtin_amdgcn_ballot_w64(busy && !found) != 0ull)
+                    hint = __shfl(s, __builtin_ctzll(hitters), 64);
             }
         }
         RT_STAMP(2)
