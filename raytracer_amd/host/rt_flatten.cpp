@@ -155,7 +155,7 @@ void build_bvh_range(std::vector<BvhItem>& items, size_t lo, size_t hi, int32_t 
     double best_c0 = 0.0, best_scale = 0.0;
     size_t best_mid = lo + n / 2;
     double best_cost = INFINITY;
-    constexpr int kBins = 16;
+    constexpr int kBins = 32;
     for (int a = 0; a < 3; ++a) {
         const double c0 = cent.mn[a], c1 = cent.mx[a];
         if (!(c1 > c0)) continue;
