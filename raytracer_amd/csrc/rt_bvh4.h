@@ -276,12 +276,88 @@ RT_DEV bool wf2_leaf(const SceneDev& S, int s, const Ray& world_ray, double limi
 struct LaneList {
     double lt[RT_LIST_CAP];
     uint32_t lid[RT_LIST_CAP];
-    uint32_t ct[RT_LIST_CAP];
     RT_DEV double& LT(int i) { return lt[i]; }
     RT_DEV uint32_t& LID(int i) { return lid[i]; }
-    RT_DEV uint32_t& CT(int i) { return ct[i]; }
     RT_DEV int cap() const { return RT_LIST_CAP; }
 };
+// The containers loop of prepare_computations (intersection.rs:50-75) on the sorted list.  containers_in_registers: the
+// reference's loop as it stands, the `containers` vector in four registers (it rarely holds more than two objects; a
+// per-lane array in private memory is shifted per entry by containers_walk of rt_trace.h); false when a fifth object would
+// have to be pushed.  containers_from_list then answers from the list alone, for any depth:
+// what the loop holds when it reaches the hit entry j* (the first entry ~equal to the hit) is the objects with an ODD number
+// of entries before j*, in the order of their last entries (an object is pushed by its 1st, 3rd, ... entry and removed by
+// its 2nd, 4th, ...; removing one does not reorder the others).  So `containers.last()` is found by going back from j*:
+// the first entry that is its object's last one before j* and whose object has an odd count there.
+//   n1 = last before the hit entry is processed (1.0 if none); the hit's object is then removed (odd count) or pushed
+//   (even); n2 = last after that.
+RT_DEV bool containers_in_registers(const SceneDev& S, LaneList& W, int n, double hit_t, double& n1, double& n2) {
+    uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    int nc = 0;
+    n1 = 1.0, n2 = 1.0;
+    auto last = [&]() { return nc == 1 ? c0 : (nc == 2 ? c1 : (nc == 3 ? c2 : c3)); };
+    for (int j = 0; j < n; ++j) {
+        const bool is_self = t_eq(W.LT(j), hit_t);
+        const uint32_t id = W.LID(j);
+        if (is_self && nc > 0) n1 = S.mats[S.shapes[last()].material].refractive_index;
+        const int pos = (nc > 0 && c0 == id) ? 0 : ((nc > 1 && c1 == id) ? 1 : ((nc > 2 && c2 == id) ? 2 : ((nc > 3 && c3 == id) ? 3 : -1)));
+        if (pos >= 0) {  // remove: the later ones move up
+            if (pos <= 0) c0 = c1;
+            if (pos <= 1) c1 = c2;
+            if (pos <= 2) c2 = c3;
+            --nc;
+        } else {
+            if (nc == 4) return false;
+            if (nc == 0) c0 = id;
+            else if (nc == 1) c1 = id;
+            else if (nc == 2) c2 = id;
+            else c3 = id;
+            ++nc;
+        }
+        if (is_self) {
+            if (nc > 0) n2 = S.mats[S.shapes[last()].material].refractive_index;
+            break;
+        }
+    }
+    return true;
+}
+RT_DEV void containers_from_list(const SceneDev& S, LaneList& W, int n, double hit_t, double& n1, double& n2) {
+    n1 = 1.0, n2 = 1.0;
+    int js = -1;
+    for (int j = 0; j < n && js < 0; ++j)
+        if (t_eq(W.LT(j), hit_t)) js = j;
+    if (js < 0) return;  // (no entry at the hit: the reference's loop runs off the list with both still 1.0)
+    const uint32_t hit_id = W.LID(js);
+    // the last container among the entries [0, js), leaving out object `skip` (0xffffffff: nobody)
+    auto last_container = [&](uint32_t skip, bool& any) -> uint32_t {
+        for (int j = js - 1; j >= 0; --j) {
+            const uint32_t id = W.LID(j);
+            if (id == skip) continue;
+            bool later = false;
+            for (int k = j + 1; k < js; ++k) later = later || W.LID(k) == id;
+            if (later) continue;  // not this object's last entry
+            unsigned count = 0;
+            for (int k = 0; k <= j; ++k) count += W.LID(k) == id ? 1u : 0u;
+            if (count & 1u) {
+                any = true;
+                return id;
+            }
+        }
+        any = false;
+        return 0u;
+    };
+    bool any = false;
+    const uint32_t before = last_container(0xffffffffu, any);
+    if (any) n1 = S.mats[S.shapes[before].material].refractive_index;
+    unsigned hit_count = 0;
+    for (int k = 0; k < js; ++k) hit_count += W.LID(k) == hit_id ? 1u : 0u;
+    if (hit_count & 1u) {  // the hit leaves its object: whoever else is last
+        const uint32_t after = last_container(hit_id, any);
+        if (any) n2 = S.mats[S.shapes[after].material].refractive_index;
+    } else {  // the hit enters its object: that object is last
+        n2 = S.mats[S.shapes[hit_id].material].refractive_index;
+    }
+}
+
 // wf2_leaf for World::intersections as a sorted list cut at t <= bound (world_list): the primitive's surviving hits are
 // inserted with BTreeSet::append's tie rule.  Returns the new length.
 template <bool STATS, int FLAT>

@@ -459,7 +459,7 @@ __global__ __launch_bounds__(64, RT_WF2_TRACE_WAVES) void wf2_trace_kernel(const
         if (busy && w.cur == RT_BVH4_DONE && p_n == 0u) {
             if constexpr (LIST) {
                 double n1, n2;
-                containers_walk(S, W, top, ctx_f(sp, slot, CX_T), n1, n2, cx);
+                if (!containers_in_registers(S, W, top, ctx_f(sp, slot, CX_T), n1, n2)) containers_from_list(S, W, top, ctx_f(sp, slot, CX_T), n1, n2);
                 ctx_f(sp, slot, CX_N1) = n1;
                 ctx_f(sp, slot, CX_N2) = n2;
             } else if constexpr (SHADOW) {

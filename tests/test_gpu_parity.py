@@ -348,3 +348,36 @@ print("ok")
     rc = N.hip.rt_hip_render_multi(flat.desc, C.byref(cd), 5, 4096, out.ctypes.data_as(C.POINTER(C.c_double)), None)
     assert rc == N.RT_ERR_INVALID_ARG  # more devices than the machine has
     assert N.hip.rt_hip_multi_transport() == b"rccl"  # /opt/rocm/lib/librccl.so is part of the image
+
+
+def test_pipeline_containers_deeper_than_four():
+    """Seven concentric glass shells among 60 other primitives, through the kernel pipeline: its containers loop keeps
+    four objects in registers and answers deeper nestings from the sorted list alone (containers_from_list); both must
+    give the n1 / n2 of intersection.rs:50-75 -- the frame equals the one-launch kernel's and the oracle's."""
+    from raytracer_amd import Material, Matrix, PointLight, Primitive, World
+    rng = np.random.default_rng(5)
+    shapes = [Primitive.new_plane().with_material(Material(color=(0.8, 0.8, 0.7), reflective=0.1))]
+    for k in range(7):
+        r = 1.6 - 0.2 * k
+        shapes.append(Primitive.new_sphere().with_transform(Matrix.chain(Matrix.translation(0, 1.7, 0), Matrix.scaling(r, r, r)))
+                      .with_material(Material(color=(0.1, 0.1 + 0.1 * k, 0.3), diffuse=0.2, transparency=0.85, reflective=0.1,
+                                              refractive_index=1.0 + 0.07 * (k + 1))))
+    for i in range(60):
+        kind = [Primitive.new_sphere, Primitive.new_cube][i % 2]
+        p = rng.uniform(-6, 6, 3)
+        s = rng.uniform(0.2, 0.5)
+        shapes.append(kind().with_transform(Matrix.chain(Matrix.translation(p[0], abs(p[1]) * 0.5 + 0.3, p[2] + 3.0), Matrix.scaling(s, s, s)))
+                      .with_material(Material(color=tuple(rng.uniform(0.2, 0.9, 3)), transparency=0.5 if i % 5 == 0 else 0.0,
+                                              refractive_index=1.3)))
+    world = World(shapes, [PointLight((-6, 9, -8), (1, 1, 1))])
+    cam = rt.Camera(240, 135, 1.0).with_transform(Matrix.view_transform((0, 2.5, -7), (0, 1.5, 0), (0, 1, 0)))
+    flat = world.flatten("global")
+    scene = rt.DeviceScene(flat)
+    one = _render_resident(scene, cam, 0)
+    two = _render_resident(scene, cam, 2)
+    scene.set_wavefront(2)
+    assert "pipeline" in scene.pipeline_name(5)
+    assert np.array_equal(one, two)
+    ref, _ = orc.OracleWorld(world.describe()).render(cam)
+    compare("glass-shells", two, ref)
+    scene.close()
