@@ -72,10 +72,11 @@ RT_DEV void ray_f32(const Ray& r, const float extent[3], float slack, RayF32& f)
     const double o[3] = {r.o.x, r.o.y, r.o.z}, d[3] = {r.d.x, r.d.y, r.d.z};
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        double inv = 1.0 / d[a];
-        // a direction component of (almost) zero: any huge finite slope says the same about every box
-        if (!(fabs(inv) <= 1e18)) inv = (d[a] < 0.0 || (d[a] == 0.0 && __double_as_longlong(d[a]) < 0)) ? -1e18 : 1e18;
-        const float invf = (float)inv;
+        // the slope in f32 from the start (d rounded, then an IEEE f32 division: 2^-23 relative together, inside the slack's
+        // budget; three f64 divisions per ray less).  A direction component of (almost) zero: any huge finite slope says
+        // the same about every box
+        float invf = 1.0f / (float)d[a];
+        if (!(fabsf(invf) <= 1e18f)) invf = (d[a] < 0.0 || (d[a] == 0.0 && __double_as_longlong(d[a]) < 0)) ? -1e18f : 1e18f;
         const double c = -o[a] * (double)invf;
         const double k = fabs((double)invf) * (double)slack * (fabs(o[a]) + (double)extent[a]);
         f.inv[a] = invf;
