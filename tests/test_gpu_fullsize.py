@@ -123,3 +123,25 @@ def test_config5_at_stated_size():
     ref, _ = orc.OracleWorld(world.describe()).render(cam, rows=(first, H, step))
     gpu = full[first::step].cpu().numpy()
     _compare("synthetic-10k-8K-rows", gpu, ref[first::step])
+
+
+def test_host_frame_in_bands_equals_one_launch():
+    """rt_hip_render hands a large f64 frame to the caller in four bands of rows, each copied (pinned staging, host copy
+    threads) while the next is traced; the caller's buffer must hold exactly what ONE launch over the whole frame writes
+    into device memory.  4096x2160 (212 MB: the band path), a recursive flat scene and one with compounds; the same frame
+    again through rt_hip_scene_render on a resident scene, and as 8-bit samples."""
+    import torch
+    for name in ("glass_bubble", "hexagon"):
+        world, cam = rt.exercise(name, 4096, 2160)
+        got = cam.render(world).pixels
+        scene = rt.DeviceScene(world.flatten())
+        H, W = cam.v_size, cam.h_size
+        dev = torch.full((H, W, 3), -3.0, dtype=torch.float64, device="cuda")
+        scene.render_rows(cam.desc(), 5, 0, 1, H, H, dev.data_ptr())
+        torch.cuda.synchronize()
+        scene.status()
+        one = dev.cpu().numpy()
+        assert np.array_equal(got, one), name
+        assert np.array_equal(scene.render(cam).pixels, one), name
+        assert np.array_equal(scene.render_rgb8(cam), orc.quantize(one)), name
+        scene.close()
