@@ -2,20 +2,19 @@
 // ("wave-front" organisation, second form).  Same functions, same arithmetic and therefore the same
 // frame, bit for bit, as render_kernel / wf_level_kernel; what changes is who does what when:
 //
-//   wf2_cands_kernel     direction-index candidates of every ray of the generation (primitive.rs:486-490's
-//                        branch, see RtDirCand) -> the ray's starting hit record / shadow flag
 //   wf2_trace_kernel     World::intersections + hit (world.rs:45-53, intersection.rs:154-158), closest hit or
-//                        shadow any-hit (world.rs:85-96): NOTHING but traversal.  Persistent waves: a lane
-//                        whose ray is done takes the next ray of the queue, so the lanes of a wave stay busy
-//                        however unequal their walks are (in wf_level_kernel two lanes in three idled).
-//                        The walk is over a 4-wide hierarchy with conservative f32 boxes (one 128-byte node
-//                        read yields four child boxes: a quarter of the dependent reads of the 2-wide
-//                        skip-link walk, box arithmetic in packed f32 instead of f64); every leaf the walk
-//                        reaches is tested with the reference's own f64 arithmetic, so no decision changes.
+//                        shadow any-hit (world.rs:85-96): NOTHING but traversal.  One-wave blocks that stay resident
+//                        and take 64 rays at a time from the launch's items (counters split 32 ways: see Wf2Counters);
+//                        a wave first evaluates its rays' direction-index candidates (primitive.rs:486-490's branch,
+//                        see RtDirCand; -DRT_WF2_CANDS_INLINE=0: wf2_cands_kernel ahead of every trace launch instead).
+//                        The walk is over a 4-wide hierarchy with conservative f32 boxes (rt_bvh4.h: one 64-byte node
+//                        read yields four child boxes: a quarter of the dependent reads of the 2-wide skip-link walk,
+//                        box arithmetic in f32 instead of f64); every leaf the walk reaches is tested with the
+//                        reference's own f64 arithmetic, so no decision changes.
 //   wf2_prepare_kernel   prepare_computations + the pattern colour (intersection.rs:45-99, pattern.rs:76-91) of
-//                        every hit; hits are compacted into shading contexts, one shadow feeler per light each
-//                        A third mode builds the sorted list of the world's intersections up to a transparent hit and
-//                        walks it for n1 / n2 (intersection.rs:50-75).  The reference lists what the whole LINE meets,
+//                        every hit into the ray's shading context (slot = ray index); one shadow feeler per light each.
+//                        A third mode of the trace kernel builds the sorted list of the world's intersections up to a
+//                        transparent hit and walks it for n1 / n2 (intersection.rs:50-75).  The reference lists what the whole LINE meets,
 //                        behind the origin too, and so does this walk.  (Measured and not adopted: closed primitives
 //                        -- sphere, cube, capped conic -- looked for only along the segment from the origin to the
 //                        hit and only the open ones along the whole line, on the grounds that an entry PAIR wholly
@@ -27,7 +26,8 @@
 //   wf2_finish_kernel    lighting per light (primitive.rs:111-151), reflected / refracted children
 //                        (world.rs:98-127, schlick intersection.rs:182-200) into the next generation's queue
 //   wf2_overflow_kernel  hits whose children found no room keep their subtree (color_at's frame stack)
-//   wf2_compact_kernel   the next generation's queue made dense
+//   wf2_scan_kernel, wf2_compact_kernel   the next generation's queue made dense, every slice sorted by where its rays
+//                        start and the octant they point into
 // and wf_combine_kernel folds children into parents from the deepest generation upwards (world.rs:76-82).
 #pragma once
 #include "rt_kernels.h"
