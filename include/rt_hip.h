@@ -346,6 +346,8 @@ int rt_hip_render_rows_noalloc(const RtScene* scene, const RtCameraDesc* cam, ui
  * 24 GB and at most half of the device's free memory (RT_HIP_WF_BUDGET_MB in the environment sets the
  * bound): larger frames are rendered in batches of rows.  If it cannot be allocated the
  * launch falls back to mode 0.
+ * Mode 2 also launches on a second stream the scene owns (forked from and joined to `hip_stream` by events inside the
+ * call: to the caller everything is ordered on `hip_stream` as before).
  * Replaces: nothing in the reference (tuning). */
 int rt_hip_scene_set_wavefront(RtScene* scene, int mode, uint64_t queue_items, uint64_t node_items);
 

@@ -24,6 +24,10 @@ struct Wf2 {
     size_t batch_pixels = 0, q_items = 0, node_items = 0;
     int trace_blocks_per_cu[2][4] = {};  // [stats][mode], from the occupancy query
     int n_cus = 0;
+    // a generation's containers walks run beside its feelers (neither reads what the other writes): a stream of the
+    // scene's own, forked from and joined to the caller's by these events (created with the scene: a launch creates nothing)
+    hipStream_t side = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
 };
 
 namespace {
@@ -549,6 +553,12 @@ int rth::wf2_create(const RtSceneDesc& d, uint32_t scene_flags, Arena& arena, Wf
         }
         w->n_cus = pd.n_cus;
         std::memcpy(w->trace_blocks_per_cu, pd.blocks, sizeof pd.blocks);
+        const char* side_env = std::getenv("RT_HIP_WF2_SIDE");
+        if (!(side_env && *side_env == '0')) {
+            HIP_TRY(hipStreamCreateWithFlags(&w->side, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&w->fork, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&w->join, hipEventDisableTiming));
+        }
         return RT_OK;
     };
     const int rc = body();
@@ -563,6 +573,9 @@ int rth::wf2_create(const RtSceneDesc& d, uint32_t scene_flags, Arena& arena, Wf
 void rth::wf2_destroy(Wf2* w) {
     if (!w) return;
     free_space(w);
+    if (w->side) (void)hipStreamDestroy(w->side);
+    if (w->fork) (void)hipEventDestroy(w->fork);
+    if (w->join) (void)hipEventDestroy(w->join);
     delete w;
 }
 
@@ -608,11 +621,20 @@ int run_pipeline(const RtScene* scene, const Wf2* w, const Wf2Space& sp, size_t 
                     hipLaunchKernelGGL((wf2_trace_kernel<ST, WF2_QUEUE>), tgrid[1], dim3(64), 0, stream, S, A, sp, *cam, rows, g, d_stats, status);
                     hipLaunchKernelGGL((wf2_prepare_kernel<ST, false>), wide, threads, 0, stream, S, A.pre, sp, *cam, rows, (int)depth, g, d_out, d_stats, status);
                 }
+                const bool more = g < depth && (S.flags & RT_SCENE_RECURSIVE);  // only hits with recursion budget left can have children
+                // the containers walks beside the feelers: each fills the tail of the other (long rays keep few waves busy)
+                const bool beside = more && w->side != nullptr;
+                if (beside) {
+                    (void)hipEventRecord(w->fork, stream);
+                    (void)hipStreamWaitEvent(w->side, w->fork, 0);
+                    hipLaunchKernelGGL((wf2_trace_kernel<ST, WF2_CONTAINERS>), tgrid[3], dim3(64), 0, w->side, S, A, sp, *cam, rows, g, d_stats, status);
+                    (void)hipEventRecord(w->join, w->side);
+                }
                 if (cands_pass) hipLaunchKernelGGL((wf2_cands_kernel<ST, WF2_SHADOW>), wide, threads, 0, stream, S, sp, *cam, rows, g, d_stats, status);
                 hipLaunchKernelGGL((wf2_trace_kernel<ST, WF2_SHADOW>), tgrid[2], dim3(64), 0, stream, S, A, sp, *cam, rows, g, d_stats, status);
-                const bool more = g < depth && (S.flags & RT_SCENE_RECURSIVE);  // only hits with recursion budget left can have children
-                if (more)
+                if (more && !beside)
                     hipLaunchKernelGGL((wf2_trace_kernel<ST, WF2_CONTAINERS>), tgrid[3], dim3(64), 0, stream, S, A, sp, *cam, rows, g, d_stats, status);
+                if (beside) (void)hipStreamWaitEvent(stream, w->join, 0);
                 hipLaunchKernelGGL((wf2_finish_kernel<ST>), wide, threads, 0, stream, S, sp, g, stretch_shift, d_out, d_stats, status);
                 if (!more) break;
                 hipLaunchKernelGGL((wf2_overflow_kernel<ST>), dim3(4096), dim3(64), 0, stream, S, sp, d_out, d_stats, status);
