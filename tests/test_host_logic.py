@@ -209,3 +209,26 @@ def test_flop_budget():
     stats["prim_tests"] = [6, 2, 0, 0, 0, 0, 0]
     assert 600 < flops.algorithmic_flops(stats) < 800
     assert flops.total_rays(stats) == 2
+
+
+def test_direction_index_cells_left_to_the_device_from_64_candidates():
+    """Flattener contract of RtSceneDesc.dir_cell_start: scenes with fewer than 64 candidate conics get their direction
+    cells from the host; from 64 on only the candidates are listed (the library rasterises the cells on the device) unless
+    the caller asks for host cells.  The candidate records are the same either way, and host-built tables are well formed
+    (offsets monotone from 0 to n_dir_entries, entries name candidates)."""
+    world, _ = rt.synthetic(64, 36, 1500)
+    dev, host = world.flatten(), world.flatten(host_cells=True)
+    a, b = dev.desc.contents, host.desc.contents
+    assert a.n_dir_cands >= 64 and a.n_dir_cands == b.n_dir_cands and a.dir_res == b.dir_res != 0
+    assert not a.dir_cell_start and not a.dir_entries and a.n_dir_entries == 0
+    n_cells = 6 * b.dir_res * b.dir_res
+    cells = np.ctypeslib.as_array(b.dir_cell_start, shape=(n_cells + 1,))
+    entries = np.ctypeslib.as_array(b.dir_entries, shape=(b.n_dir_entries,))
+    assert cells[0] == 0 and cells[-1] == b.n_dir_entries and (np.diff(cells.astype(np.int64)) >= 0).all()
+    assert entries.max() < b.n_dir_cands
+    import ctypes as C
+    size = C.sizeof(a.dir_cands.contents) * a.n_dir_cands
+    assert C.string_at(a.dir_cands, size) == C.string_at(b.dir_cands, size)
+    small, _ = rt.exercise("cover", 64, 36)
+    s = small.flatten().desc.contents
+    assert s.n_dir_cands < 64 and (s.n_dir_cands == 0 or bool(s.dir_cell_start))
