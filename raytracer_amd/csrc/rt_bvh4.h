@@ -17,6 +17,8 @@ struct __attribute__((aligned(64))) Bvh4Node {
 static_assert(sizeof(Bvh4Node) == 64, "one node = four 16-byte words: half the words of f32 boxes (the walk is bound by its vector memory instructions)");
 #define RT_BVH4_LEAF 0x80000000u
 #define RT_BVH4_DONE 0x7fffffffu
+#define RT_BVH4_NOPRE 0x40000000u  // in a leaf code: the leaf has no f32 pre-test (planes, triangles): its record is read for the ancestors only
+#define RT_BVH4_SHAPE(code) ((code) & 0x3fffffffu)
 #ifndef RT_WF2_LDS_STACK
 #define RT_WF2_LDS_STACK 24   // stack entries per lane kept in LDS; deeper ones in private memory
 #endif
@@ -432,19 +434,24 @@ RT_DEV bool trace4(const SceneDev& S, const Ray& ray, bool shadow, double limit,
         if (w.sp < RT_TRACE4_LDS_STACK) lds_stack[w.sp * 256] = w.cur;
         else deep[w.sp - RT_TRACE4_LDS_STACK] = w.cur;
         ++w.sp;
-        w.cur = RT_BVH4_LEAF | A.always[k];
+        w.cur = RT_BVH4_LEAF | A.always[k];  // (always[] carries RT_BVH4_NOPRE where it applies)
     }
     for (;;) {
         // box tests only, until this lane holds a leaf or is through: the lanes of a wave meet again at the leaves
         while (w.cur < RT_BVH4_DONE) walk_step<RT_TRACE4_LDS_STACK, 256>(A, f, 0.f, t_far, w, lds_stack, deep, cx);
         if (w.cur == RT_BVH4_DONE) break;
-        const int s = (int)(w.cur & ~RT_BVH4_LEAF);
+        const int s = (int)RT_BVH4_SHAPE(w.cur);
         bool worth = true;
         uint32_t anc0 = RT_PRE_DEEP, anc1 = RT_PRE_NO_ANC;
         if (A.pre) {
-            const float reach = fmaxf(fmaxf(fabsf((float)ray.o.x), fabsf((float)ray.o.y)), fabsf((float)ray.o.z)) * 1.000001f + A.extent_max;
-            worth = leaf_may_hit(A.pre + s, ray, reach, anc0, anc1);
-            count(cx, ST_BVH_BOX);
+            if (w.cur & RT_BVH4_NOPRE) {
+                const uint2 anc = *reinterpret_cast<const uint2*>(&A.pre[s].anc[0]);
+                anc0 = anc.x, anc1 = anc.y;
+            } else {
+                const float reach = fmaxf(fmaxf(fabsf((float)ray.o.x), fabsf((float)ray.o.y)), fabsf((float)ray.o.z)) * 1.000001f + A.extent_max;
+                worth = leaf_may_hit(A.pre + s, ray, reach, anc0, anc1);
+                count(cx, ST_BVH_BOX);
+            }
         }
         if (worth) {
             if (shadow) {

@@ -415,17 +415,22 @@ __global__ __launch_bounds__(64, RT_WF2_TRACE_WAVES) void wf2_trace_kernel(const
                 if (hint < 0) break;  // (the same in every lane)
                 take = busy && !found;
                 keep_walk = true;
-                leaf = RT_BVH4_LEAF | (uint32_t)hint;
+                leaf = RT_BVH4_LEAF | (uint32_t)hint;  // (pre-tested again: the hint carries no flag)
             }
-            const int s = (int)(leaf & ~RT_BVH4_LEAF);
+            const int s = (int)RT_BVH4_SHAPE(leaf);
             bool hit_shadow = false;
             if (take) {
                 bool worth = true;
                 uint32_t anc0 = RT_PRE_DEEP, anc1 = RT_PRE_NO_ANC;
                 if (A.pre) {
-                    const float reach = fmaxf(fmaxf(fabsf((float)ray.o.x), fabsf((float)ray.o.y)), fabsf((float)ray.o.z)) * 1.000001f + A.extent_max;
-                    worth = leaf_may_hit(A.pre + s, ray, reach, anc0, anc1);
-                    count(cx, ST_BVH_BOX);  // one more acceleration-only test
+                    if (leaf & RT_BVH4_NOPRE) {  // no pre-test for this kind: the record is read for the ancestors only
+                        const uint2 anc = *reinterpret_cast<const uint2*>(&A.pre[s].anc[0]);
+                        anc0 = anc.x, anc1 = anc.y;
+                    } else {
+                        const float reach = fmaxf(fmaxf(fabsf((float)ray.o.x), fabsf((float)ray.o.y)), fabsf((float)ray.o.z)) * 1.000001f + A.extent_max;
+                        worth = leaf_may_hit(A.pre + s, ray, reach, anc0, anc1);
+                        count(cx, ST_BVH_BOX);  // one more acceleration-only test
+                    }
                 }
                 if (worth) {
                     if constexpr (LIST)

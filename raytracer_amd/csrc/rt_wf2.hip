@@ -418,6 +418,7 @@ int rth::wf2_create(const RtSceneDesc& d, uint32_t scene_flags, Arena& arena, Wf
     // What the pipeline covers: a world-level hierarchy whose leaves are primitives (nested in groups or not), no CSG
     // node and no shadowless primitive anywhere (those need the sorted world list per ray: the older kernels have it).
     if (d.world_bvh_root < 0 || (scene_flags & RT_SCENE_HAS_SHADOWLESS) || d.n_csgs != 0 || d.n_lights == 0) return RT_OK;
+    if (d.n_shapes >= RT_BVH4_NOPRE) return RT_OK;  // (a leaf code keeps its top two bits for flags)
     std::vector<TNode> tree;
     std::vector<uint32_t> top;
     if (!parse_seq(d, d.world_bvh_root, -1, tree, top, 0) || top.empty()) return RT_OK;
@@ -507,6 +508,16 @@ int rth::wf2_create(const RtSceneDesc& d, uint32_t scene_flags, Arena& arena, Wf
             if (chain.size() > 2) p.anc[0] = RT_PRE_DEEP;
             else for (size_t k = 0; k < chain.size(); ++k) p.anc[k] = (uint32_t)chain[chain.size() - 1 - k];
         }
+    {  // leaves without a pre-test say so in their code (the walk then reads two of the record's five words)
+        auto flag = [&](uint32_t code) {
+            if ((code & RT_BVH4_LEAF) && code != RT_BVH4_DONE && pre[RT_BVH4_SHAPE(code)].kind == RT_PRE_NONE) code |= RT_BVH4_NOPRE;
+            return code;
+        };
+        for (Bvh4Node& nd : b.nodes)
+            for (int c = 0; c < 4; ++c) nd.child[c] = (int32_t)flag((uint32_t)nd.child[c]);
+        w->accel.root = flag(w->accel.root), w->accel.root_open = flag(w->accel.root_open);
+        for (uint32_t k = 0; k < w->accel.n_always; ++k) w->accel.always[k] = flag(RT_BVH4_LEAF | w->accel.always[k]) & ~RT_BVH4_LEAF;
+    }
     auto env_or = [](const char* name, unsigned dflt, unsigned lo, unsigned hi) {
         const char* e = std::getenv(name);
         const long v = e && *e ? std::atol(e) : 0;
