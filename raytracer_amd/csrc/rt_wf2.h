@@ -193,6 +193,9 @@ __global__ __launch_bounds__(256) void wf2_cands_kernel(const SceneDev S, Wf2Spa
 #ifndef RT_WF2_SHADOW_HINT
 #define RT_WF2_SHADOW_HINT 0  // measured: 21.3 ms with, 21.0 without (most feelers of this scene reach their light; the extra test is paid by all)
 #endif
+#ifndef RT_WF2_MIN_CHUNK
+#define RT_WF2_MIN_CHUNK 8u
+#endif
 #ifndef RT_WF2_PEND
 #define RT_WF2_PEND 4
 #endif
@@ -227,7 +230,19 @@ __global__ __launch_bounds__(64, RT_WF2_TRACE_WAVES) void wf2_trace_kernel(const
     // the parts of the request list.  A wave starts at its block's home part and moves on when a part is used up.
     const unsigned n = MODE == WF2_PRIMARY ? pm.n_items : (MODE == WF2_QUEUE ? sp.cnt->n_rays[gen] : (LIST ? 0u : n_hits * S.n_lights));
     Wf2Padded* chunk_counters = sp.cnt->chunk[3u * gen + (SHADOW ? 1u : (LIST ? 2u : 0u))];
-    const unsigned per_part = LIST ? sp.creq_part_cap : ((n + A.chunk - 1u) / A.chunk + RT_WF2_PARTS - 1u) / RT_WF2_PARTS * A.chunk;
+    // Rays a wave takes at a time: A.chunk (64) when the launch has that many for every resident wave, fewer when it has
+    // not -- a wave runs as long as its slowest ray, so a small launch (a late generation, a narrow band of a multi-GPU
+    // frame) is through sooner as many waves of 8-32 rays than as a few full ones with the rest of the device idle.
+    unsigned chunk = A.chunk;
+    {
+        unsigned total = n;
+        if constexpr (LIST) {
+            total = 0;
+            for (unsigned p = 0; p < RT_WF2_PARTS; ++p) total += sp.cnt->n_creq[p].v;
+        }
+        while (chunk > RT_WF2_MIN_CHUNK && (unsigned long long)gridDim.x * chunk > total) chunk >>= 1;
+    }
+    const unsigned per_part = LIST ? sp.creq_part_cap : ((n + chunk - 1u) / chunk + RT_WF2_PARTS - 1u) / RT_WF2_PARTS * chunk;
     unsigned part = blockIdx.x % RT_WF2_PARTS, parts_left = RT_WF2_PARTS;
     unsigned part_lo = part * per_part;
     unsigned part_hi = LIST ? part_lo + sp.cnt->n_creq[part].v : (part_lo + per_part < n ? part_lo + per_part : n);
@@ -263,12 +278,12 @@ __global__ __launch_bounds__(64, RT_WF2_TRACE_WAVES) void wf2_trace_kernel(const
             while (chunk_next >= chunk_end && !dry) {
                 unsigned c = 0xffffffffu;
                 if (part_lo < part_hi) {
-                    if (lane == 0) c = atomicAdd(&chunk_counters[part].v, A.chunk);
+                    if (lane == 0) c = atomicAdd(&chunk_counters[part].v, chunk);
                     c = (unsigned)__builtin_amdgcn_readfirstlane((int)c);
                 }
                 if (c < part_hi - part_lo && part_lo < part_hi) {
                     chunk_next = part_lo + c;
-                    chunk_end = chunk_next + A.chunk < part_hi ? chunk_next + A.chunk : part_hi;
+                    chunk_end = chunk_next + chunk < part_hi ? chunk_next + chunk : part_hi;
                 } else if (--parts_left == 0u) {
                     dry = true;
                 } else {  // this part is used up: on to the next

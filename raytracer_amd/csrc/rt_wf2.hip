@@ -612,10 +612,12 @@ int run_pipeline(const RtScene* scene, const Wf2* w, const Wf2Space& sp, size_t 
         constexpr bool ST = decltype(stats_tag)::value;
         const dim3 tgrid[4] = {dim3((unsigned)(w->n_cus * w->trace_blocks_per_cu[ST][0])), dim3((unsigned)(w->n_cus * w->trace_blocks_per_cu[ST][1])),
                                dim3((unsigned)(w->n_cus * w->trace_blocks_per_cu[ST][2])), dim3((unsigned)(w->n_cus * w->trace_blocks_per_cu[ST][3]))};
-        // children of a stretch of 2^shift consecutive hits share a shard: large enough to keep neighbours together, small
-        // enough that every shard gets many stretches
+        // children of a stretch of 2^shift consecutive hits share a shard (picked by a hash of the stretch): large enough to
+        // keep neighbours together, small enough that every shard gets MANY stretches -- a shard's slice of the queue holds
+        // 1.5 x its fair share, and with 8 stretches per shard (a 1/8 share of a 4K frame under the old rule) the hash left
+        // some shards with twice theirs: their hits overflowed into wf2_overflow_kernel, 5.8 ms against 2.5 for the share
         unsigned stretch_shift = 6;
-        while (stretch_shift < RT_WF_CHUNK_SHIFT && ((size_t)sp.ctx_cap >> (stretch_shift + 1)) >= 8u * RT_WF_SHARDS) ++stretch_shift;
+        while (stretch_shift < RT_WF_CHUNK_SHIFT && ((size_t)sp.ctx_cap >> (stretch_shift + 1)) >= 64u * RT_WF_SHARDS) ++stretch_shift;
         for (uint32_t row0 = 0; row0 < rows_in.n_local_rows; row0 += (uint32_t)batch_rows) {
             RowMap rows = rows_in;
             rows.row0 = row0;
