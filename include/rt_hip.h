@@ -342,7 +342,7 @@ int rt_hip_render_rows_noalloc(const RtScene* scene, const RtCameraDesc* cam, ui
  * time; when they run out the affected hits keep their subtrees to themselves (mode-0 behaviour:
  * slower, same result).  The workspace belongs to the scene and is allocated -- with a device
  * synchronisation when it has to grow -- by the first launch that needs it: mode 1 about 640 B per
- * pixel of the frame (scaled down to fit the same bound as mode 2's); mode 2 about 460 B per pixel (4 GB at 4096 x 2160, 15 GB at 7680 x 4320), at most
+ * pixel of the frame (scaled down to fit the same bound as mode 2's); mode 2 about 680 B per pixel (6 GB at 4096 x 2160, 22 GB at 7680 x 4320), at most
  * 24 GB and at most half of the device's free memory (RT_HIP_WF_BUDGET_MB in the environment sets the
  * bound): larger frames are rendered in batches of rows.  If it cannot be allocated the
  * launch falls back to mode 0.

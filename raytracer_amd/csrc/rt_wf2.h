@@ -23,8 +23,10 @@
 //                        edge of a cube behind the origin with a chord under 1e-5 has its two entries merged into
 //                        ONE by the set's dedupe (primitive.rs:227-230), an odd count that the reference keeps in
 //                        `containers`: one pixel of 1.1 M differed at 7680x4320.  RT_HIP_WF2_SEG_NEAR=1 runs it.)
-//   wf2_finish_kernel    lighting per light (primitive.rs:111-151), reflected / refracted children
-//                        (world.rs:98-127, schlick intersection.rs:182-200) into the next generation's queue
+//   wf2_spawn_kernel     reflected / refracted children (world.rs:98-127, schlick intersection.rs:182-200) into the node
+//                        pool and the next generation's queue: the next generation starts from here
+//   wf2_light_kernel     lighting per light (primitive.rs:111-151) with the feelers' answers -- with the feelers on the
+//                        scene's second stream, off the critical path (contexts are double-buffered by generation)
 //   wf2_overflow_kernel  hits whose children found no room keep their subtree (color_at's frame stack)
 //   wf2_scan_kernel, wf2_compact_kernel   the next generation's queue made dense, every slice sorted by where its rays
 //                        start and the octant they point into
@@ -44,7 +46,10 @@ struct Wf2Hit {  // closest hit of one colour ray
 // wave read and write consecutive words.
 enum { CX_OVER = 0, CX_UNDER = 3, CX_EYE = 6, CX_NORMAL = 9, CX_REFLECT = 12, CX_COLOR = 15, CX_SURFACE = 18,
        CX_T = 21, CX_N1 = 22, CX_N2 = 23, CX_DOUBLES = 24 };
-enum { CU_MAT = 0, CU_PARENT = 1, CU_REMAINING = 2, CU_ITEM = 3, CU_UINTS = 4 };
+enum { CU_MAT = 0, CU_PARENT = 1, CU_REMAINING = 2, CU_ITEM = 3, CU_NODE = 4, CU_UINTS = 5 };
+// CU_NODE: where the hit's lit surface colour goes -- the node wf2_spawn_kernel made for it, or one of
+#define RT_WF2_NODE_NONE 0xffffffffu     // no children: the colour straight to whoever waits for this ray
+#define RT_WF2_NODE_REFUSED 0xfffffffeu  // children found no room: into the context (CX_SURFACE), for wf2_overflow_kernel
 
 // Counters many waves bump at once are split RT_WF2_PARTS ways, one 128-byte line each: atomics on ONE address are
 // served one after the other (~11 ns each, measured: a second per-wave atomic doubled wf2_prepare_kernel's time), and a
@@ -58,8 +63,7 @@ struct alignas(128) Wf2Padded {
 };
 struct Wf2Counters {
     unsigned n_rays[RT_WF_LEVELS + 1];  // colour rays of generation g (dense queue length)
-    unsigned n_hits;                    // shading context slots of the generation at hand (= its colour rays: slot i is ray i's)
-    unsigned n_overflow;
+    unsigned n_overflow[RT_WF_LEVELS + 1];  // per generation: hits whose children found no room
     Wf2Padded n_creq[RT_WF2_PARTS];     // containers requests (transparent hits), per part of the request list
     Wf2Padded chunk[3 * (RT_WF_LEVELS + 1)][RT_WF2_PARTS];  // next chunk of each trace launch (generation x {colour, shadow, containers}) per part of its items
     unsigned offsets[RT_WF_SHARDS * RT_WF_BINS + 1];  // compaction: start of each (shard, octant) sub-slice in the dense queue
@@ -75,6 +79,12 @@ struct Wf2Space {
     uint8_t* occ;      // [n_lights][ctx_cap]: light l is hidden from hit `slot`
     uint32_t* creq;    // [RT_WF2_PARTS][creq_part_cap]: slots whose hit is transparent, by part (see wf2_prepare_kernel)
     uint32_t* overflow;  // [ctx_cap]
+    // Generation g works in buffer set g & 1 of these four (the host swaps the pointers above per generation): its feelers
+    // and lighting run on a second stream while generation g + 1 is already traced and prepared into the other set.
+    double* alt_ctx_d;
+    uint32_t* alt_ctx_u;
+    uint8_t* alt_occ;
+    uint32_t* alt_overflow;
     Wf2Counters* cnt;
     unsigned qd_cap, ctx_cap, creq_part_cap;
 };
@@ -100,6 +110,8 @@ RT_DEV PixelMap pixel_map(const RtCameraDesc& cam, const RowMap& rows) {
     m.n_items = m.tiles_x * ((rows.batch_rows + 7u) / 8u) * 64u;
     return m;
 }
+// shading context slots of generation `gen` = its colour rays (slot i is ray i's)
+RT_DEV unsigned wf2_n_slots(const Wf2Space& sp, unsigned gen, const PixelMap& pm) { return gen == 0u ? pm.n_items : sp.cnt->n_rays[gen]; }
 // -> false for the slots of a tile that fall outside the frame; k = local row, y = image row
 RT_DEV bool pixel_of_item(const RtCameraDesc& cam, const RowMap& rows, const PixelMap& m, unsigned i, unsigned& x, unsigned& k,
                           unsigned& y) {
@@ -166,7 +178,7 @@ __global__ __launch_bounds__(256) void wf2_cands_kernel(const SceneDev S, Wf2Spa
         for (int i = 0; i < ST_COUNT; ++i) cx.cnt[i] = 0;
     }
     const PixelMap pm = pixel_map(cam, rows);
-    const unsigned n_hits = MODE == WF2_SHADOW ? sp.cnt->n_hits : 0u;
+    const unsigned n_hits = MODE == WF2_SHADOW ? wf2_n_slots(sp, gen, pm) : 0u;
     const unsigned n = MODE == WF2_PRIMARY ? pm.n_items : (MODE == WF2_QUEUE ? sp.cnt->n_rays[gen] : n_hits * S.n_lights);
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         Ray ray;
@@ -225,7 +237,7 @@ __global__ __launch_bounds__(64, RT_WF2_TRACE_WAVES) void wf2_trace_kernel(const
         for (int i = 0; i < ST_COUNT; ++i) cx.cnt[i] = 0;
     }
     const PixelMap pm = pixel_map(cam, rows);
-    const unsigned n_hits = SHADOW ? sp.cnt->n_hits : 0u;
+    const unsigned n_hits = SHADOW ? wf2_n_slots(sp, gen, pm) : 0u;
     // The launch's items in RT_WF2_PARTS parts, each with a counter of its own: equal stretches of the item range, or (LIST)
     // the parts of the request list.  A wave starts at its block's home part and moves on when a part is used up.
     const unsigned n = MODE == WF2_PRIMARY ? pm.n_items : (MODE == WF2_QUEUE ? sp.cnt->n_rays[gen] : (LIST ? 0u : n_hits * S.n_lights));
@@ -659,13 +671,13 @@ __global__ __launch_bounds__(256, RT_WF2_PREP_WAVES) void wf2_prepare_kernel(con
             ctx_u(sp, slot, CU_PARENT) = parent;
             ctx_u(sp, slot, CU_REMAINING) = remaining;
             ctx_u(sp, slot, CU_ITEM) = i;
+            ctx_u(sp, slot, CU_NODE) = RT_WF2_NODE_NONE;
         }
         // requests for n1 / n2 go to the part of the list that belongs to this group of four waves
         const unsigned creq_part = (i >> 8) % RT_WF2_PARTS;
         const unsigned r = wave_slots(&sp.cnt->n_creq[creq_part].v, want_n);
         if (want_n) sp.creq[(size_t)creq_part * sp.creq_part_cap + r] = slot;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) sp.cnt->n_hits = n;
     flush_stats(cx, stats, status);
 }
 
@@ -685,7 +697,8 @@ RT_DEV void ctx_shade(const SceneDev& S, const Wf2Space& sp, unsigned slot, Shad
 // Returns false for a lane whose request found no room (its pieces that did fit are blanked).
 RT_DEV bool wf2_commit(const WfSpace& ws, unsigned shard, unsigned level, bool want, uint32_t parent, V3 surface,
                        double reflective, double transparency, const Children& ch, V3 reflect_o, V3 reflect_d,
-                       int remaining_children) {
+                       int remaining_children, uint32_t& node_out) {
+    node_out = RT_WF2_NODE_NONE;
     const unsigned long long asking = __builtin_amdgcn_ballot_w64(want);
     if (asking == 0ull) return false;
     const unsigned lane = __lane_id();
@@ -723,6 +736,7 @@ RT_DEV bool wf2_commit(const WfSpace& ws, unsigned shard, unsigned level, bool w
     n.parent = parent;
     n.flags = (ch.use_schlick ? WF_USE_SCHLICK : 0u) | (ch.do_reflect ? WF_HAS_REFLECT : 0u) | (ch.do_refract ? WF_HAS_REFRACT : 0u);
     const uint32_t global_node = (uint32_t)((size_t)shard * ws.node_cap + ni);
+    node_out = global_node;
     if (has0) {
         WfItem& it = q[s0];
         it.ray = Ray{reflect_o, reflect_d}, it.parent = global_node << 1, it.remaining = (uint32_t)remaining_children;
@@ -734,13 +748,20 @@ RT_DEV bool wf2_commit(const WfSpace& ws, unsigned shard, unsigned level, bool w
     return true;
 }
 
-// shade_hit from its light loop on (world.rs:58-82) for every hit of the generation: lighting per light with the
-// feelers' answers, then the children -- into the node pool and the next generation's queue (wf_commit), or, for a
-// hit that has none, the colour straight to whoever waits for it.
+// shade_hit (world.rs:55-83) of every hit of the generation, in two kernels on two streams:
+//   wf2_spawn_kernel (the caller's stream, after the containers walks): the children -- reflected / refracted rays,
+//       Schlick (world.rs:72-82 as far as it needs no colour yet) -- into the node pool and the next generation's queue
+//       (wf2_commit); the hit's context remembers its node.  The next generation starts from here.
+//   wf2_light_kernel (the scene's second stream, after the generation's feelers): lighting per light (world.rs:58-70) with the
+//       feelers' answers; the surface colour goes into the hit's node, or -- a hit without children -- straight to whoever
+//       waits for it, or -- children refused for want of room -- into the context for wf2_overflow_kernel.
+// Feelers are two thirds of all rays and nothing downstream of a generation needs their answers before the frame's colours
+// are folded together at the very end: off the critical path they fill the device while the colour rays' launches, each as
+// long as its slowest wave, come and go.
 template <bool STATS>
-__global__ __launch_bounds__(256, RT_WF2_FINISH_WAVES) void wf2_finish_kernel(const SceneDev S, Wf2Space sp, unsigned gen, unsigned stretch_shift,
-                                                         double* __restrict__ out, RtStats* __restrict__ stats,
-                                                         unsigned* __restrict__ status) {
+__global__ __launch_bounds__(256, RT_WF2_FINISH_WAVES) void wf2_spawn_kernel(const SceneDev S, Wf2Space sp, RtCameraDesc cam, RowMap rows, unsigned gen,
+                                                                            unsigned stretch_shift, RtStats* __restrict__ stats,
+                                                                            unsigned* __restrict__ status) {
     constexpr int CLS = RT_CLASS_NESTED_LEAVES;
     Ctx<STATS, CLS> cx;
     cx.status = 0;
@@ -748,7 +769,7 @@ __global__ __launch_bounds__(256, RT_WF2_FINISH_WAVES) void wf2_finish_kernel(co
 #pragma unroll
         for (int i = 0; i < ST_COUNT; ++i) cx.cnt[i] = 0;
     }
-    const unsigned n = sp.cnt->n_hits;
+    const unsigned n = wf2_n_slots(sp, gen, pixel_map(cam, rows));
     const unsigned n_round = (n + 63u) & ~63u;
     for (unsigned slot = blockIdx.x * blockDim.x + threadIdx.x; slot < n_round; slot += gridDim.x * blockDim.x) {
         const bool active = slot < n && ctx_u(sp, slot < n ? slot : 0u, CU_MAT) != 0xffffffffu;
@@ -765,31 +786,66 @@ __global__ __launch_bounds__(256, RT_WF2_FINISH_WAVES) void wf2_finish_kernel(co
             ctx_shade(S, sp, slot, sd, remaining);
             parent = ctx_u(sp, slot, CU_PARENT);
             const RtMaterial m = S.mats[sd.mat];
-            for (unsigned l = 0; l < S.n_lights; ++l) {  // world.rs:58-70, in light order
-                const RtLight light = S.lights[l];
-                const bool occluded = sp.occ[(size_t)l * n + slot] != 0;
-                sd.surface = sd.surface + lighting(m, sd.color, light, sd.over, sd.eye, sd.normal, occluded, cx);
-            }
             reflective = m.reflective, transparency = m.transparency;
             shade_children(m, sd, Ray{sd.over, sd.reflect_v}, (int)remaining, ch, cx);
             want = ch.do_reflect || ch.do_refract;
         }
         // a wave's children go to the shard picked by where they come from: a stretch of consecutive hits
         const unsigned out_shard = (((unsigned)__builtin_amdgcn_readfirstlane((int)slot) >> stretch_shift) * 2654435761u) >> 24;
-        const bool placed = wf2_commit(sp.ws, out_shard, gen, want, parent, sd.surface, reflective, transparency, ch, sd.over,
-                                      sd.reflect_v, (int)remaining - 1);
+        uint32_t node;
+        const bool placed = wf2_commit(sp.ws, out_shard, gen, want, parent, v3(0.0, 0.0, 0.0), reflective, transparency, ch, sd.over,
+                                      sd.reflect_v, (int)remaining - 1, node);
         if (placed) {
             if (ch.do_reflect) count(cx, ST_RAY_REFLECT);
             if (ch.do_refract) count(cx, ST_RAY_REFRACT);
-        } else if (active && !want) {
-            wf_deliver(sp.ws.nodes, out, parent,
-                       combine(sd.surface, v3(0.0, 0.0, 0.0), v3(0.0, 0.0, 0.0), ch.use_schlick, ch.reflectance));
+            ctx_u(sp, slot, CU_NODE) = node;
         }
         const bool refused = want && !placed;
-        const unsigned r = wave_slots(&sp.cnt->n_overflow, refused);
+        const unsigned r = wave_slots(&sp.cnt->n_overflow[gen], refused);
         if (refused) {
-            ctx_put(sp, slot, CX_SURFACE, sd.surface);
+            ctx_u(sp, slot, CU_NODE) = RT_WF2_NODE_REFUSED;
             sp.overflow[r] = slot;
+        }
+    }
+    flush_stats(cx, stats, status);
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(256, RT_WF2_FINISH_WAVES) void wf2_light_kernel(const SceneDev S, Wf2Space sp, RtCameraDesc cam, RowMap rows, unsigned gen,
+                                                                            double* __restrict__ out, RtStats* __restrict__ stats,
+                                                                            unsigned* __restrict__ status) {
+    constexpr int CLS = RT_CLASS_NESTED_LEAVES;
+    Ctx<STATS, CLS> cx;
+    cx.status = 0;
+    if constexpr (STATS) {
+#pragma unroll
+        for (int i = 0; i < ST_COUNT; ++i) cx.cnt[i] = 0;
+    }
+    const unsigned n = wf2_n_slots(sp, gen, pixel_map(cam, rows));
+    for (unsigned slot = blockIdx.x * blockDim.x + threadIdx.x; slot < n; slot += gridDim.x * blockDim.x) {
+        if (ctx_u(sp, slot, CU_MAT) == 0xffffffffu) continue;  // no hit in this slot
+        Shade sd;
+        uint32_t remaining = 0;
+        ctx_shade(S, sp, slot, sd, remaining);
+        sd.surface = v3(0.0, 0.0, 0.0);
+        const RtMaterial m = S.mats[sd.mat];
+        for (unsigned l = 0; l < S.n_lights; ++l) {  // world.rs:58-70, in light order
+            const RtLight light = S.lights[l];
+            const bool occluded = sp.occ[(size_t)l * n + slot] != 0;
+            sd.surface = sd.surface + lighting(m, sd.color, light, sd.over, sd.eye, sd.normal, occluded, cx);
+        }
+        const uint32_t node = ctx_u(sp, slot, CU_NODE);
+        if (node == RT_WF2_NODE_REFUSED) {
+            ctx_put(sp, slot, CX_SURFACE, sd.surface);
+        } else if (node != RT_WF2_NODE_NONE) {
+            sp.ws.nodes[node].surface = sd.surface;
+        } else {  // no children: world.rs:76-82 with both of them black
+            Children ch;
+            Ctx<false, CLS> quiet;  // (wf2_spawn_kernel counted the Schlick evaluation, if this generation had one)
+            quiet.status = 0;
+            shade_children(m, sd, Ray{sd.over, sd.reflect_v}, (int)remaining, ch, quiet);
+            wf_deliver(sp.ws.nodes, out, ctx_u(sp, slot, CU_PARENT),
+                       combine(sd.surface, v3(0.0, 0.0, 0.0), v3(0.0, 0.0, 0.0), ch.use_schlick, ch.reflectance));
         }
     }
     flush_stats(cx, stats, status);
@@ -798,7 +854,7 @@ __global__ __launch_bounds__(256, RT_WF2_FINISH_WAVES) void wf2_finish_kernel(co
 // Hits whose children found no room in the queue or the node pool: the lane keeps the subtree (color_at's frame
 // stack), exactly as world.rs:98-127 recurse.  Capacity costs speed, never the result.
 template <bool STATS>
-__global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void wf2_overflow_kernel(const SceneDev S, Wf2Space sp, double* __restrict__ out,
+__global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void wf2_overflow_kernel(const SceneDev S, Wf2Space sp, unsigned gen, double* __restrict__ out,
                                                                              RtStats* __restrict__ stats, unsigned* __restrict__ status) {
     constexpr int CLS = RT_CLASS_NESTED_LEAVES;
     Ctx<STATS, CLS> cx;
@@ -807,7 +863,7 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void wf2_overflow_kernel(con
 #pragma unroll
         for (int i = 0; i < ST_COUNT; ++i) cx.cnt[i] = 0;
     }
-    const unsigned n = sp.cnt->n_overflow;
+    const unsigned n = sp.cnt->n_overflow[gen];
     for (unsigned r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
         const unsigned slot = sp.overflow[r];
         Shade sd;
@@ -853,7 +909,6 @@ __global__ __launch_bounds__(RT_WF_SHARDS) void wf2_scan_kernel(Wf2Space sp, uns
         }
         sp.cnt->offsets[RT_WF_SHARDS] = run;
         sp.cnt->n_rays[gen + 1u] = run;
-        sp.cnt->n_hits = 0u, sp.cnt->n_overflow = 0u;
     }
     if (s < RT_WF2_PARTS) sp.cnt->n_creq[s].v = 0u;
 }

@@ -27,7 +27,7 @@ struct Wf2 {
     // a generation's containers walks run beside its feelers (neither reads what the other writes): a stream of the
     // scene's own, forked from and joined to the caller's by these events (created with the scene: a launch creates nothing)
     hipStream_t side = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
+    hipEvent_t prepared[RT_WF_LEVELS + 1] = {}, spawned[RT_WF_LEVELS + 1] = {}, lit[RT_WF_LEVELS + 1] = {};
 };
 
 namespace {
@@ -321,7 +321,7 @@ Plan plan_for(size_t items, size_t q_items, size_t node_items, uint32_t n_lights
     p.qd_cap = p.q_cap * RT_WF_SHARDS;
     p.ctx_cap = std::max(items, p.qd_cap);
     p.bytes = 2 * p.qd_cap * sizeof(WfItem) + p.node_cap * RT_WF_SHARDS * sizeof(WfNode) + p.ctx_cap * sizeof(Wf2Hit) +
-              p.ctx_cap * (CX_DOUBLES * sizeof(double) + CU_UINTS * sizeof(uint32_t) + 2 * sizeof(uint32_t) + n_lights) +
+              2 * p.ctx_cap * (CX_DOUBLES * sizeof(double) + CU_UINTS * sizeof(uint32_t) + sizeof(uint32_t) + n_lights) + p.ctx_cap * sizeof(uint32_t) +
               (size_t)RT_WF2_PARTS * 256u * sizeof(uint32_t) + sizeof(Wf2Counters) + 16u * 256u;
     return p;
 }
@@ -348,6 +348,10 @@ bool carve_space(Wf2Space& s, unsigned char* base, size_t bytes, const Plan& p, 
     take(&s.occ, p.ctx_cap * (n_lights ? n_lights : 1u));
     take(&s.creq, (size_t)RT_WF2_PARTS * wf2_creq_part_cap(p.ctx_cap) * sizeof(uint32_t));
     take(&s.overflow, p.ctx_cap * sizeof(uint32_t));
+    take(&s.alt_ctx_d, p.ctx_cap * CX_DOUBLES * sizeof(double));
+    take(&s.alt_ctx_u, p.ctx_cap * CU_UINTS * sizeof(uint32_t));
+    take(&s.alt_occ, p.ctx_cap * (n_lights ? n_lights : 1u));
+    take(&s.alt_overflow, p.ctx_cap * sizeof(uint32_t));
     take(&s.cnt, sizeof(Wf2Counters));
     s.ws.q_cap = (unsigned)p.q_cap, s.ws.node_cap = (unsigned)p.node_cap;
     s.qd_cap = (unsigned)p.qd_cap, s.ctx_cap = (unsigned)p.ctx_cap;
@@ -397,6 +401,10 @@ int ensure_space(Wf2* w, size_t items, size_t q_items, size_t node_items, uint32
     get(&s.occ, p.ctx_cap * (n_lights ? n_lights : 1u));
     get(&s.creq, (size_t)RT_WF2_PARTS * wf2_creq_part_cap(p.ctx_cap) * sizeof(uint32_t));
     get(&s.overflow, p.ctx_cap * sizeof(uint32_t));
+    get(&s.alt_ctx_d, p.ctx_cap * CX_DOUBLES * sizeof(double));
+    get(&s.alt_ctx_u, p.ctx_cap * CU_UINTS * sizeof(uint32_t));
+    get(&s.alt_occ, p.ctx_cap * (n_lights ? n_lights : 1u));
+    get(&s.alt_overflow, p.ctx_cap * sizeof(uint32_t));
     get(&s.cnt, sizeof(Wf2Counters));
     if (rc != RT_OK) {
         (void)hipGetLastError();
@@ -567,8 +575,11 @@ int rth::wf2_create(const RtSceneDesc& d, uint32_t scene_flags, Arena& arena, Wf
         const char* side_env = std::getenv("RT_HIP_WF2_SIDE");
         if (!(side_env && *side_env == '0')) {
             HIP_TRY(hipStreamCreateWithFlags(&w->side, hipStreamNonBlocking));
-            HIP_TRY(hipEventCreateWithFlags(&w->fork, hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&w->join, hipEventDisableTiming));
+            for (int g = 0; g <= RT_WF_LEVELS; ++g) {
+                HIP_TRY(hipEventCreateWithFlags(&w->prepared[g], hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&w->spawned[g], hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&w->lit[g], hipEventDisableTiming));
+            }
         }
         return RT_OK;
     };
@@ -585,8 +596,9 @@ void rth::wf2_destroy(Wf2* w) {
     if (!w) return;
     free_space(w);
     if (w->side) (void)hipStreamDestroy(w->side);
-    if (w->fork) (void)hipEventDestroy(w->fork);
-    if (w->join) (void)hipEventDestroy(w->join);
+    for (int g = 0; g <= RT_WF_LEVELS; ++g)
+        for (hipEvent_t e : {w->prepared[g], w->spawned[g], w->lit[g]})
+            if (e) (void)hipEventDestroy(e);
     delete w;
 }
 
@@ -624,35 +636,51 @@ int run_pipeline(const RtScene* scene, const Wf2* w, const Wf2Space& sp, size_t 
             rows.batch_rows = (uint32_t)std::min<size_t>(batch_rows, rows_in.n_local_rows - row0);
             (void)hipMemsetAsync(sp.ws.shards, 0, RT_WF_SHARDS * sizeof(WfShard), stream);
             (void)hipMemsetAsync(sp.cnt, 0, sizeof(Wf2Counters), stream);
+            // Generation g works in buffer set g & 1 (contexts, feeler answers, overflow list).  The caller's stream carries
+            // what the next generation waits for -- closest hits, contexts, containers walks, children, the queue made
+            // dense --, the scene's second stream the generation's feelers, its lighting and its overflow subtrees.
+            const bool two = w->side != nullptr;
+            hipStream_t side = two ? w->side : stream;
+            unsigned last = 0;
             for (unsigned g = 0; g <= depth; ++g) {
+                last = g;
+                Wf2Space spg = sp;
+                if (g & 1u) spg.ctx_d = sp.alt_ctx_d, spg.ctx_u = sp.alt_ctx_u, spg.occ = sp.alt_occ, spg.overflow = sp.alt_overflow;
+                if (two && g >= 2u) (void)hipStreamWaitEvent(stream, w->lit[g - 2u], 0);  // this set's last readers are through
                 if (g == 0) {
-                    if (cands_pass) hipLaunchKernelGGL((wf2_cands_kernel<ST, WF2_PRIMARY>), wide, threads, 0, stream, S, sp, *cam, rows, g, d_stats, status);
-                    hipLaunchKernelGGL((wf2_trace_kernel<ST, WF2_PRIMARY>), tgrid[0], dim3(64), 0, stream, S, A, sp, *cam, rows, g, d_stats, status);
-                    hipLaunchKernelGGL((wf2_prepare_kernel<ST, true>), wide, threads, 0, stream, S, A.pre, sp, *cam, rows, (int)depth, g, d_out, d_stats, status);
+                    if (cands_pass) hipLaunchKernelGGL((wf2_cands_kernel<ST, WF2_PRIMARY>), wide, threads, 0, stream, S, spg, *cam, rows, g, d_stats, status);
+                    hipLaunchKernelGGL((wf2_trace_kernel<ST, WF2_PRIMARY>), tgrid[0], dim3(64), 0, stream, S, A, spg, *cam, rows, g, d_stats, status);
+                    hipLaunchKernelGGL((wf2_prepare_kernel<ST, true>), wide, threads, 0, stream, S, A.pre, spg, *cam, rows, (int)depth, g, d_out, d_stats, status);
                 } else {
-                    if (cands_pass) hipLaunchKernelGGL((wf2_cands_kernel<ST, WF2_QUEUE>), wide, threads, 0, stream, S, sp, *cam, rows, g, d_stats, status);
-                    hipLaunchKernelGGL((wf2_trace_kernel<ST, WF2_QUEUE>), tgrid[1], dim3(64), 0, stream, S, A, sp, *cam, rows, g, d_stats, status);
-                    hipLaunchKernelGGL((wf2_prepare_kernel<ST, false>), wide, threads, 0, stream, S, A.pre, sp, *cam, rows, (int)depth, g, d_out, d_stats, status);
+                    if (cands_pass) hipLaunchKernelGGL((wf2_cands_kernel<ST, WF2_QUEUE>), wide, threads, 0, stream, S, spg, *cam, rows, g, d_stats, status);
+                    hipLaunchKernelGGL((wf2_trace_kernel<ST, WF2_QUEUE>), tgrid[1], dim3(64), 0, stream, S, A, spg, *cam, rows, g, d_stats, status);
+                    hipLaunchKernelGGL((wf2_prepare_kernel<ST, false>), wide, threads, 0, stream, S, A.pre, spg, *cam, rows, (int)depth, g, d_out, d_stats, status);
                 }
+                if (two) {
+                    (void)hipEventRecord(w->prepared[g], stream);
+                    (void)hipStreamWaitEvent(side, w->prepared[g], 0);
+                }
+                if (cands_pass) hipLaunchKernelGGL((wf2_cands_kernel<ST, WF2_SHADOW>), wide, threads, 0, side, S, spg, *cam, rows, g, d_stats, status);
+                hipLaunchKernelGGL((wf2_trace_kernel<ST, WF2_SHADOW>), tgrid[2], dim3(64), 0, side, S, A, spg, *cam, rows, g, d_stats, status);
                 const bool more = g < depth && (S.flags & RT_SCENE_RECURSIVE);  // only hits with recursion budget left can have children
-                // the containers walks beside the feelers: each fills the tail of the other (long rays keep few waves busy)
-                const bool beside = more && w->side != nullptr;
-                if (beside) {
-                    (void)hipEventRecord(w->fork, stream);
-                    (void)hipStreamWaitEvent(w->side, w->fork, 0);
-                    hipLaunchKernelGGL((wf2_trace_kernel<ST, WF2_CONTAINERS>), tgrid[3], dim3(64), 0, w->side, S, A, sp, *cam, rows, g, d_stats, status);
-                    (void)hipEventRecord(w->join, w->side);
+                if (more) {
+                    hipLaunchKernelGGL((wf2_trace_kernel<ST, WF2_CONTAINERS>), tgrid[3], dim3(64), 0, stream, S, A, spg, *cam, rows, g, d_stats, status);
+                    hipLaunchKernelGGL((wf2_spawn_kernel<ST>), wide, threads, 0, stream, S, spg, *cam, rows, g, stretch_shift, d_stats, status);
+                    if (two) {
+                        (void)hipEventRecord(w->spawned[g], stream);
+                        (void)hipStreamWaitEvent(side, w->spawned[g], 0);
+                    }
                 }
-                if (cands_pass) hipLaunchKernelGGL((wf2_cands_kernel<ST, WF2_SHADOW>), wide, threads, 0, stream, S, sp, *cam, rows, g, d_stats, status);
-                hipLaunchKernelGGL((wf2_trace_kernel<ST, WF2_SHADOW>), tgrid[2], dim3(64), 0, stream, S, A, sp, *cam, rows, g, d_stats, status);
-                if (more && !beside)
-                    hipLaunchKernelGGL((wf2_trace_kernel<ST, WF2_CONTAINERS>), tgrid[3], dim3(64), 0, stream, S, A, sp, *cam, rows, g, d_stats, status);
-                if (beside) (void)hipStreamWaitEvent(stream, w->join, 0);
-                hipLaunchKernelGGL((wf2_finish_kernel<ST>), wide, threads, 0, stream, S, sp, g, stretch_shift, d_out, d_stats, status);
+                hipLaunchKernelGGL((wf2_light_kernel<ST>), wide, threads, 0, side, S, spg, *cam, rows, g, d_out, d_stats, status);
+                if (more) hipLaunchKernelGGL((wf2_overflow_kernel<ST>), dim3(4096), dim3(64), 0, side, S, spg, g, d_out, d_stats, status);
+                if (two) (void)hipEventRecord(w->lit[g], side);
                 if (!more) break;
-                hipLaunchKernelGGL((wf2_overflow_kernel<ST>), dim3(4096), dim3(64), 0, stream, S, sp, d_out, d_stats, status);
-                hipLaunchKernelGGL(wf2_scan_kernel, dim3(1), dim3(RT_WF_SHARDS), 0, stream, sp, g);
-                hipLaunchKernelGGL(wf2_compact_kernel, dim3(RT_WF_SHARDS), threads, 0, stream, sp, g, A.extent[0], A.extent[1], A.extent[2]);
+                hipLaunchKernelGGL(wf2_scan_kernel, dim3(1), dim3(RT_WF_SHARDS), 0, stream, spg, g);
+                hipLaunchKernelGGL(wf2_compact_kernel, dim3(RT_WF_SHARDS), threads, 0, stream, spg, g, A.extent[0], A.extent[1], A.extent[2]);
+            }
+            if (two) {  // every colour is where the folding below (and the next batch, and the caller) expects it
+                (void)hipStreamWaitEvent(stream, w->lit[last], 0);
+                if (last >= 1u) (void)hipStreamWaitEvent(stream, w->lit[last - 1u], 0);
             }
             if (S.flags & RT_SCENE_RECURSIVE)
                 for (unsigned k = depth; k-- > 0;) rth::launch_combine(sp.ws, k, d_out, stream);
