@@ -695,9 +695,20 @@ RT_DEV void ctx_shade(const SceneDev& S, const Wf2Space& sp, unsigned slot, Shad
 // wf_commit for the pipeline: a node per asking lane and its child rays into the shard's slice of the sliced queue,
 // the wave's reflected rays first, then its refracted ones; two atomics per wave.  Every lane of the wave calls it.
 // Returns false for a lane whose request found no room (its pieces that did fit are blanked).
+// The wave's nodes are consecutive in the pool and its items consecutive in the slice, but a lane's 128-byte node written
+// with per-lane stores touches 64 different lines per instruction (the kernel was bound by exactly that: 75 % of its time
+// in the texture-address units, 1.4 % in the ALUs).  So the records are put together in LDS -- `stage`: RT_WF2_STAGE_WORDS
+// 8-byte words of the calling wave's own, record strides of 17 and 9 words so that the lanes' field stores spread over the
+// banks -- and leave in whole 512-byte rows.
+#define RT_WF2_STAGE_WORDS 1152u  // max(64 nodes x 17, 128 items x 9) 8-byte words
+RT_DEV void wf2_lds_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 RT_DEV bool wf2_commit(const WfSpace& ws, unsigned shard, unsigned level, bool want, uint32_t parent, V3 surface,
                        double reflective, double transparency, const Children& ch, V3 reflect_o, V3 reflect_d,
-                       int remaining_children, uint32_t& node_out) {
+                       int remaining_children, uint32_t& node_out, uint2* stage) {
     node_out = RT_WF2_NODE_NONE;
     const unsigned long long asking = __builtin_amdgcn_ballot_w64(want);
     if (asking == 0ull) return false;
@@ -707,45 +718,70 @@ RT_DEV bool wf2_commit(const WfSpace& ws, unsigned shard, unsigned level, bool w
     const bool has0 = want && ch.do_reflect, has1 = want && ch.do_refract;
     const unsigned long long m0 = __builtin_amdgcn_ballot_w64(has0), m1 = __builtin_amdgcn_ballot_w64(has1);
     const unsigned n0 = (unsigned)__builtin_popcountll(m0), n1 = (unsigned)__builtin_popcountll(m1);
+    const unsigned n_ask = (unsigned)__builtin_popcountll(asking);
     const int leader = __builtin_ctzll(asking);
     unsigned base_nodes = 0u, base_items = 0u;
     if ((int)lane == leader) {
-        base_nodes = atomicAdd(&sh.nodes_asked[level], (unsigned)__builtin_popcountll(asking));
+        base_nodes = atomicAdd(&sh.nodes_asked[level], n_ask);
         base_items = atomicAdd(&sh.items[(level + 1u) & 1u][0], n0 + n1);
     }
     base_nodes = (unsigned)__shfl((int)base_nodes, leader, 64);
     base_items = (unsigned)__shfl((int)base_items, leader, 64);
-    if (!want) return false;
-    const unsigned long long ni = (unsigned long long)sh.node_begin[level] + base_nodes + (unsigned)__builtin_popcountll(asking & below);
-    const unsigned long long s0 = (unsigned long long)base_items + (unsigned)__builtin_popcountll(m0 & below);
-    const unsigned long long s1 = (unsigned long long)base_items + n0 + (unsigned)__builtin_popcountll(m1 & below);
+    const unsigned rank = (unsigned)__builtin_popcountll(asking & below);
+    const unsigned i0 = (unsigned)__builtin_popcountll(m0 & below), i1 = n0 + (unsigned)__builtin_popcountll(m1 & below);  // items of the wave
+    const unsigned long long ni0 = (unsigned long long)sh.node_begin[level] + base_nodes;
+    const unsigned long long ni = ni0 + rank;
+    const unsigned long long s0 = (unsigned long long)base_items + i0, s1 = (unsigned long long)base_items + i1;
     const bool fit0 = !has0 || s0 < ws.q_cap, fit1 = !has1 || s1 < ws.q_cap;
+    const bool placed = want && ni < ws.node_cap && fit0 && fit1;
     WfItem* __restrict__ q = ws.queue[(level + 1u) & 1u] + (size_t)shard * ws.q_cap;
     WfNode* __restrict__ nodes = ws.nodes + (size_t)shard * ws.node_cap;
-    if (!(ni < ws.node_cap && fit0 && fit1)) {
-        if (ni < ws.node_cap) nodes[ni].flags = WF_DEAD;
-        if (has0 && fit0) q[s0].remaining = RT_WF_EMPTY;
-        if (has1 && fit1) q[s1].remaining = RT_WF_EMPTY;
-        return false;
-    }
-    WfNode& n = nodes[ni];
-    n.surface = surface;
-    n.child[0] = v3(0.0, 0.0, 0.0);
-    n.child[1] = v3(0.0, 0.0, 0.0);
-    n.reflective = reflective, n.transparency = transparency, n.reflectance = ch.reflectance;
-    n.parent = parent;
-    n.flags = (ch.use_schlick ? WF_USE_SCHLICK : 0u) | (ch.do_reflect ? WF_HAS_REFLECT : 0u) | (ch.do_refract ? WF_HAS_REFRACT : 0u);
     const uint32_t global_node = (uint32_t)((size_t)shard * ws.node_cap + ni);
-    node_out = global_node;
-    if (has0) {
-        WfItem& it = q[s0];
-        it.ray = Ray{reflect_o, reflect_d}, it.parent = global_node << 1, it.remaining = (uint32_t)remaining_children;
+    // ---- nodes
+    if (want && ni < ws.node_cap) {
+        double* d = reinterpret_cast<double*>(stage + rank * 17u);
+        uint32_t* u = reinterpret_cast<uint32_t*>(d + 12);
+        d[0] = surface.x, d[1] = surface.y, d[2] = surface.z;
+        d[3] = 0.0, d[4] = 0.0, d[5] = 0.0, d[6] = 0.0, d[7] = 0.0, d[8] = 0.0;  // child[0], child[1]
+        d[9] = reflective, d[10] = transparency, d[11] = ch.reflectance;
+        u[0] = parent;
+        u[1] = !placed ? (uint32_t)WF_DEAD
+                       : (ch.use_schlick ? WF_USE_SCHLICK : 0u) | (ch.do_reflect ? WF_HAS_REFLECT : 0u) | (ch.do_refract ? WF_HAS_REFRACT : 0u);
+        d[13] = 0.0, d[14] = 0.0, d[15] = 0.0;  // pad
     }
-    if (has1) {
-        WfItem& it = q[s1];
-        it.ray = ch.refract_ray, it.parent = (global_node << 1) | 1u, it.remaining = (uint32_t)remaining_children;
+    wf2_lds_wave_sync();
+    {
+        const unsigned n_valid = ni0 >= ws.node_cap ? 0u : (n_ask < ws.node_cap - ni0 ? n_ask : (unsigned)(ws.node_cap - ni0));
+        uint2* __restrict__ g = reinterpret_cast<uint2*>(nodes + ni0);
+        for (unsigned i = lane; i < n_valid * 16u; i += 64u) g[i] = stage[(i >> 4) * 17u + (i & 15u)];
     }
-    return true;
+    wf2_lds_wave_sync();
+    // ---- items
+    if (has0 && fit0) {
+        double* d = reinterpret_cast<double*>(stage + i0 * 9u);
+        uint32_t* u = reinterpret_cast<uint32_t*>(d + 6);
+        d[0] = reflect_o.x, d[1] = reflect_o.y, d[2] = reflect_o.z, d[3] = reflect_d.x, d[4] = reflect_d.y, d[5] = reflect_d.z;
+        u[0] = global_node << 1, u[1] = placed ? (uint32_t)remaining_children : RT_WF_EMPTY;
+        d[7] = 0.0;  // pad
+    }
+    if (has1 && fit1) {
+        double* d = reinterpret_cast<double*>(stage + i1 * 9u);
+        uint32_t* u = reinterpret_cast<uint32_t*>(d + 6);
+        const Ray r = ch.refract_ray;
+        d[0] = r.o.x, d[1] = r.o.y, d[2] = r.o.z, d[3] = r.d.x, d[4] = r.d.y, d[5] = r.d.z;
+        u[0] = (global_node << 1) | 1u, u[1] = placed ? (uint32_t)remaining_children : RT_WF_EMPTY;
+        d[7] = 0.0;
+    }
+    wf2_lds_wave_sync();
+    {
+        const unsigned n_items = n0 + n1;
+        const unsigned n_valid = base_items >= ws.q_cap ? 0u : (n_items < ws.q_cap - base_items ? n_items : ws.q_cap - base_items);
+        uint2* __restrict__ g = reinterpret_cast<uint2*>(q + base_items);
+        for (unsigned i = lane; i < n_valid * 8u; i += 64u) g[i] = stage[(i >> 3) * 9u + (i & 7u)];
+    }
+    wf2_lds_wave_sync();  // (the next call's stores must not overtake these reads)
+    if (placed) node_out = global_node;
+    return placed;
 }
 
 // shade_hit (world.rs:55-83) of every hit of the generation, in two kernels on two streams:
@@ -769,6 +805,8 @@ __global__ __launch_bounds__(256, RT_WF2_FINISH_WAVES) void wf2_spawn_kernel(con
 #pragma unroll
         for (int i = 0; i < ST_COUNT; ++i) cx.cnt[i] = 0;
     }
+    __shared__ uint2 stage_all[4u * RT_WF2_STAGE_WORDS];  // (256-thread blocks)
+    uint2* stage = stage_all + (threadIdx.x >> 6) * RT_WF2_STAGE_WORDS;
     const unsigned n = wf2_n_slots(sp, gen, pixel_map(cam, rows));
     const unsigned n_round = (n + 63u) & ~63u;
     for (unsigned slot = blockIdx.x * blockDim.x + threadIdx.x; slot < n_round; slot += gridDim.x * blockDim.x) {
@@ -794,7 +832,7 @@ __global__ __launch_bounds__(256, RT_WF2_FINISH_WAVES) void wf2_spawn_kernel(con
         const unsigned out_shard = (((unsigned)__builtin_amdgcn_readfirstlane((int)slot) >> stretch_shift) * 2654435761u) >> 24;
         uint32_t node;
         const bool placed = wf2_commit(sp.ws, out_shard, gen, want, parent, v3(0.0, 0.0, 0.0), reflective, transparency, ch, sd.over,
-                                      sd.reflect_v, (int)remaining - 1, node);
+                                      sd.reflect_v, (int)remaining - 1, node, stage);
         if (placed) {
             if (ch.do_reflect) count(cx, ST_RAY_REFLECT);
             if (ch.do_refract) count(cx, ST_RAY_REFRACT);

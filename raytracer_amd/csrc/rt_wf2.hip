@@ -787,5 +787,5 @@ int rth::wf2_render_noalloc(const RtScene* scene, const RtCameraDesc* cam, uint3
 
 const char* rth::wf2_describe() {
     return "kernel pipeline per generation of rays: wf2_trace_kernel (4-wide f32 hierarchy, persistent waves) for colour rays, "
-           "shadow feelers and containers walks + wf2_prepare / wf2_finish / wf2_overflow / wf2_compact + wf_combine_kernel";
+           "shadow feelers and containers walks + wf2_prepare / wf2_spawn / wf2_light / wf2_overflow / wf2_compact + wf_combine_kernel";
 }
