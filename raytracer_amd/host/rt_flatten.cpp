@@ -106,10 +106,34 @@ ABox primitive_box(const Primitive& p, const Matrix4& to_target) {
 // primitives' own boxes, each carried up through the composed transforms.  (Transforming a compound's
 // box as a box, level by level, inflates it at every rotated level; in the 10 000-primitive scene that
 // was a third more box tests and group entries per ray.)
+//
+// A CSG node's box only has to hold this: a ray whose line misses it gets no hit from the node.  An operand the line
+// misses contributes no entries and never toggles its in_l / in_r flag (compound.rs:142-168), and then
+//   Difference   (l_hit && !in_r) || (!l_hit && in_l): without left entries nothing passes  -> the LEFT operand's box;
+//   Intersection (l_hit && in_r) || (!l_hit && in_l): without either operand's entries nothing passes -> EITHER operand's
+//                box, the smaller one;
+//   Union        -> both.
+// (Exact whatever the toggles do at grazed edges, where two ~equal hits dedupe into one and a flag stays set for the rest
+// of the line: the argument needs "no entries", not "inside".  The geometric intersection of the operands' boxes would
+// NOT do: a left hit far outside the right operand's box passes the filter once in_r is stuck.)
+// csg.rs: tricylinder 2.2^3 -> one cylinder's box, ball 5.7 x 2 x 5.7 -> the sphere's box, hollowed_box 2.8^3 -> 2^3.
 ABox tight_box(const Shape& s, const Matrix4& to_target) {
     if (s.is_primitive()) return primitive_box(s.primitive(), to_target);
     const Compound& c = s.compound();
     const Matrix4 m = to_target * c.properties().transform;
+    if (c.kind() == Compound::Kind::Csg && c.operation() != Operation::Union) {
+        const ABox l = tight_box(c.children()[0], m), r = tight_box(c.children()[1], m);
+        if (c.operation() == Operation::Difference) {
+            if (!l.empty() || l.unbounded) return l;
+        } else if (!l.empty() && !r.empty()) {
+            if (l.unbounded) return r;
+            if (r.unbounded) return l;
+            return l.half_area() <= r.half_area() ? l : r;
+        }
+        ABox b = l;
+        b.merge(r);
+        return b;
+    }
     ABox b;
     for (const Shape& child : c.children()) b.merge(tight_box(child, m));
     return b;
