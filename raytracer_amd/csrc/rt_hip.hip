@@ -195,9 +195,18 @@ int validate(const RtSceneDesc& d, uint32_t* flags_out) {
                 const RtGroup& g = d.groups[s.param];
                 if (g.bvh_root < -1 || g.bvh_root >= (int32_t)d.n_bvh_nodes) return RT_ERR_INVALID_SCENE;
                 if ((g.n_children == 0) != (s.skip == i + 1)) return RT_ERR_INVALID_SCENE;
-                if (g.bvh_root >= 0)  // CSG operands are always scanned linearly (direction index contract)
-                    for (uint32_t a : open)
-                        if (RT_KIND(d.shapes[a].kind_flags) == RT_CSG) return RT_ERR_INVALID_SCENE;
+                if (g.bvh_root >= 0) {
+                    // inside a CSG node only a group with no cylinder or cone below it may carry a tree: such a primitive can
+                    // return a hit outside its box, which the direction index makes up for at the world level and for whole
+                    // CSG nodes only
+                    bool in_csg = false;
+                    for (uint32_t a : open) in_csg = in_csg || RT_KIND(d.shapes[a].kind_flags) == RT_CSG;
+                    if (in_csg)
+                        for (uint32_t c = i + 1; c < s.skip && c < d.n_shapes; ++c) {
+                            const unsigned ck = RT_KIND(d.shapes[c].kind_flags);
+                            if (ck == RT_CYLINDER || ck == RT_CONE) return RT_ERR_INVALID_SCENE;
+                        }
+                }
             } else {
                 if (s.param >= d.n_csgs) return RT_ERR_INVALID_SCENE;
                 const RtCsg& c = d.csgs[s.param];

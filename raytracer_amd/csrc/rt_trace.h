@@ -457,13 +457,15 @@ RT_DEV int cand_next(const SceneDev& S, const Ray& ray, CandIter& it, Ray& r, in
 // Group members go straight into the list of the nearest enclosing CSG node (or the root
 // list): a group's merge is a set union with the tie rule of list_insert.  A CSG node gets a
 // sub-list of its own, filtered when its subtree is done and then merged downwards.
-// With USE_BVH the world level and groups that carry an acceleration structure are walked
-// through it (groups inside CSG nodes never carry one: see the flattener).
+// USE_BVH 1: the world level (its hierarchy and the direction candidates first) and groups that carry an acceleration
+// structure are walked through it; 2: a subtree on its own, only the groups' structures (inside a CSG node a group has
+// one only if no cylinder or cone sits below it: see the flattener); 0: linear scans throughout.
 // Shape::intersect / Compound::local_intersect / World::intersections
 // (shape.rs:28-32, compound.rs:87-117, world.rs:45-53).
-template <bool USE_BVH, bool STATS, int FLAT, class SW>
+template <int USE_BVH, bool STATS, int FLAT, class SW>
 RT_DEV int list_eval_core(const SceneDev& S, SW& W, int begin, int end, int level0, int base0, int top0,
                           double bound, Ctx<STATS, FLAT>& cx) {
+    constexpr bool WALK = USE_BVH != 0, WORLD = USE_BVH == 1;
     int level = level0;
     int floor = level0;  // the level whose exhaustion ends the current source (candidate or walk)
     int top = top0;
@@ -472,9 +474,9 @@ RT_DEV int list_eval_core(const SceneDev& S, SW& W, int begin, int end, int leve
     Ray ray = ray0;
     // with acceleration structures in play, the direction candidates come first, each as a
     // one-shape pseudo level; then the walk proper (USE_BVH is only used from the world level)
-    bool in_cands = USE_BVH && S.dir_res != 0u;
+    bool in_cands = WORLD && S.dir_res != 0u;
     CandIter it;
-    if (USE_BVH && in_cands) cand_begin(S, ray0, it);
+    if (WORLD && in_cands) cand_begin(S, ray0, it);
     bool bvh = false;
     int cur = 0, lend = 0;  // nothing at hand: the first pass through the loop picks a source
     bool started = false;
@@ -482,7 +484,7 @@ RT_DEV int list_eval_core(const SceneDev& S, SW& W, int begin, int end, int leve
     V3 inv_d = v3(0.0, 0.0, 0.0);
     for (;;) {
         int s = -1;
-        if (USE_BVH && bvh) {
+        if (WALK && bvh) {
             while (cur >= 0) {
                 const RtBvhNode nd = S.bvh[cur];  // 32 bytes: two 16-byte reads
                 count(cx, ST_BVH_BOX);
@@ -504,7 +506,7 @@ RT_DEV int list_eval_core(const SceneDev& S, SW& W, int begin, int end, int leve
         }
         if (s < 0) {  // level exhausted
             if (level == floor) {
-                if (FLAT == RT_CLASS_NESTED_LEAVES && USE_BVH && resume >= -1) {  // back from a nested CSG node to the world walk
+                if (FLAT == RT_CLASS_NESTED_LEAVES && WORLD && resume >= -1) {  // back from a nested CSG node to the world walk
                     level = floor = level0;
                     ray = ray0;
                     bvh = true;
@@ -513,7 +515,7 @@ RT_DEV int list_eval_core(const SceneDev& S, SW& W, int begin, int end, int leve
                     inv_d = v3(1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z);
                     continue;
                 }
-                if (USE_BVH && in_cands) {  // next direction candidate, or on to the walk
+                if (WORLD && in_cands) {  // next direction candidate, or on to the walk
                     int n;
                     Ray r;
                     const int node = cand_next(S, ray0, it, r, n, cx);
@@ -531,10 +533,10 @@ RT_DEV int list_eval_core(const SceneDev& S, SW& W, int begin, int end, int leve
                 started = true;
                 level = floor = level0;
                 ray = ray0;
-                bvh = USE_BVH && S.world_bvh_root >= 0;
+                bvh = WORLD && S.world_bvh_root >= 0;
                 cur = bvh ? S.world_bvh_root : begin;
                 lend = end;
-                if (USE_BVH && bvh) inv_d = v3(1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z);
+                if (WORLD && bvh) inv_d = v3(1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z);
                 continue;
             }
             const int g = W.fnode[level];
@@ -550,14 +552,14 @@ RT_DEV int list_eval_core(const SceneDev& S, SW& W, int begin, int end, int leve
             ray = W.rays[level];
             cur = W.cur[level];
             lend = W.end[level];
-            bvh = USE_BVH && lend == -2;
-            if (USE_BVH && bvh) inv_d = v3(1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z);
+            bvh = WALK && lend == -2;
+            if (WALK && bvh) inv_d = v3(1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z);
             continue;
         }
         const RtShape* __restrict__ sh = S.shapes + s;
         const unsigned kf = sh->kind_flags;
         const unsigned kind = RT_KIND(kf);
-        if (FLAT == RT_CLASS_NESTED_LEAVES && USE_BVH && level == level0 && floor == level0 && level0 == 0 &&
+        if (FLAT == RT_CLASS_NESTED_LEAVES && WORLD && level == level0 && floor == level0 && level0 == 0 &&
             sh->parent >= 0 && kind != RT_GROUP) {
             // a nested shape named directly by the world-level hierarchy (see trace): a primitive is met
             // through its ancestors right here; a CSG node becomes a one-shape pseudo level, like a
@@ -604,7 +606,7 @@ RT_DEV int list_eval_core(const SceneDev& S, SW& W, int begin, int end, int leve
             const RtGroup* __restrict__ g = S.groups + sh->param;
             count(cx, ST_GATES);
             if (g->n_children == 0u || !box_intersects(g->bmin, g->bmax, lr)) continue;  // compound.rs:93-95
-            root = USE_BVH ? g->bvh_root : -1;
+            root = WALK ? g->bvh_root : -1;
         }
         W.rays[level] = ray;
         W.cur[level] = cur;
@@ -614,8 +616,8 @@ RT_DEV int list_eval_core(const SceneDev& S, SW& W, int begin, int end, int leve
         W.fbase[level] = base;
         if (kind == RT_CSG) base = top;
         ray = lr;
-        bvh = USE_BVH && root >= 0;
-        if (USE_BVH && bvh) {
+        bvh = WALK && root >= 0;
+        if (WALK && bvh) {
             cur = root;
             inv_d = v3(1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z);
         } else {
@@ -630,7 +632,7 @@ RT_DEV int list_eval_core(const SceneDev& S, SW& W, int begin, int end, int leve
 template <bool STATS, int FLAT, class SW>
 RT_DEV_COLD int list_eval(const SceneDev& S, SW& W, int begin, int end, int level0, int base0, double bound,
                      Ctx<STATS, FLAT>& cx) {
-    return list_eval_core<false>(S, W, begin, end, level0, base0, base0, bound, cx);
+    return list_eval_core<2>(S, W, begin, end, level0, base0, base0, bound, cx);
 }
 
 // ---- streaming world traversal ---------------------------------------------------
@@ -722,7 +724,7 @@ RT_DEV int world_list(const SceneDev& S, SW& W, const Ray& ray, double bound, Ct
         return top;
     } else {
     W.rays[0] = ray;
-    return list_eval_core<true>(S, W, 0, (int)S.n_shapes, 0, 0, top, bound, cx);
+    return list_eval_core<1>(S, W, 0, (int)S.n_shapes, 0, 0, top, bound, cx);
     }
 }
 

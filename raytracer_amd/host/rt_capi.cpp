@@ -1,4 +1,5 @@
 // C handle API (include/rt_host.h) over the C++ host mirror.
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -336,6 +337,7 @@ RthFlat* rth_world_flatten(const RthWorld* w, int build_bvh) {
         opt.build_bvh = form != 0;
         opt.hierarchy = form >= 2 ? form - 1 : 0;  // 2: nested, 3: global
         if (build_bvh & 8) opt.dir_device_min = static_cast<size_t>(-1);  // +8: the direction index's cells built here, whatever the count
+        if (const char* e = std::getenv("RT_FLATTEN_DIR_RES")) opt.dir_res = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));  // study knob (0: no index, results may differ)
         auto* f = new RthFlat{flatten(w->w, opt), {}};
         f->desc = f->flat.desc();
         return f;

@@ -139,6 +139,15 @@ ABox tight_box(const Shape& s, const Matrix4& to_target) {
     return b;
 }
 
+// Cylinders and cones can return a hit outside their box (primitive.rs:486-490: a ray parallel to the surface, no y-range
+// check); the direction index makes up for that at the world level and for whole CSG nodes, not inside one.
+bool holds_conic(const Shape& s) {
+    if (s.is_primitive()) return s.primitive().kind() == Primitive::Kind::Cylinder || s.primitive().kind() == Primitive::Kind::Cone;
+    for (const Shape& child : s.compound().children())
+        if (holds_conic(child)) return true;
+    return false;
+}
+
 // f32 bounds that contain the f64 ones
 inline float round_down(double x) {
     float f = static_cast<float>(x);
@@ -396,14 +405,16 @@ struct Flattener {
             rec.param = static_cast<uint32_t>(out.groups.size());
             out.groups.push_back(g);
             const size_t group_slot = rec.param;
+            // a group inside a CSG node gets a hierarchy of its own only if no cylinder or cone sits below it (csg.rs: the
+            // twelve wedges the ball is cut with)
+            const bool tree = opt.build_bvh && !global && (csg_depth == 0 || !holds_conic(s));
             std::vector<BvhItem> items;
             for (const Shape& child : c.children()) {
                 const uint32_t child_idx = static_cast<uint32_t>(out.shapes.size());
                 emit(child, static_cast<int32_t>(idx), depth + 1, global ? to_world * c.properties().transform : to_world);
-                if (opt.build_bvh && !global && csg_depth == 0)
-                    items.push_back(BvhItem{tight_box(child, Matrix4::identity()), child_idx});
+                if (tree) items.push_back(BvhItem{tight_box(child, Matrix4::identity()), child_idx});
             }
-            if (opt.build_bvh && !global && csg_depth == 0 && wants_bvh(c.children().size(), c.children()))
+            if (tree && wants_bvh(c.children().size(), c.children()))
                 out.groups[group_slot].bvh_root = build_bvh(items, out.bvh_nodes);
         } else {
             rec.kind_flags |= static_cast<uint32_t>(c.operation()) << RT_FLAG_CSG_OP_SHIFT;
