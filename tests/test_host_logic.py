@@ -232,3 +232,62 @@ def test_direction_index_cells_left_to_the_device_from_64_candidates():
     small, _ = rt.exercise("cover", 64, 36)
     s = small.flatten().desc.contents
     assert s.n_dir_cands < 64 and (s.n_dir_cands == 0 or bool(s.dir_cell_start))
+
+
+def _world_leaf_box(d, shape):
+    for k in range(d.n_bvh_nodes):
+        nd = d.bvh_nodes[k]
+        if nd.shape == shape:
+            return np.array(list(nd.bmin)), np.array(list(nd.bmax))
+    raise AssertionError("no leaf names shape %d" % shape)
+
+
+def test_csg_box_is_the_operand_whose_absence_empties_the_node():  # compound.rs:142-181
+    # difference: nothing passes the filter without left entries -> the left operand's box; intersection: the smaller
+    # operand's; union: both.  (Boxes are padded by 1e-4 of their diagonal and rounded outwards to f32.)
+    small = Primitive.new_cube().with_transform(Matrix.scaling(0.5, 0.5, 0.5))
+    big = Primitive.new_sphere().with_transform(Matrix.chain(Matrix.translation(3, 0, 0), Matrix.scaling(2, 2, 2)))
+    other = Primitive.new_sphere().with_transform(Matrix.translation(0, 9, 0))  # (a second top-level shape: a hierarchy is built)
+    for op, lo, hi in ((Operation.Difference, (-0.5,) * 3, (0.5,) * 3),
+                       (Operation.Intersection, (-0.5,) * 3, (0.5,) * 3),
+                       (Operation.Union, (-0.5, -2, -2), (5, 2, 2))):
+        for left, right in ((small, big), (big, small)):
+            if op == Operation.Difference and left is big:
+                lo_, hi_ = (1, -2, -2), (5, 2, 2)
+            else:
+                lo_, hi_ = lo, hi
+            flat = World([rt.Compound.new_csg(op, left, right), other], []).flatten()
+            d = flat.desc.contents
+            assert d.world_bvh_root >= 0
+            bmin, bmax = _world_leaf_box(d, 0)
+            assert (bmin <= np.array(lo_)).all() and (bmin >= np.array(lo_) - 0.01).all()
+            assert (bmax >= np.array(hi_)).all() and (bmax <= np.array(hi_) + 0.01).all()
+            assert create(flat.desc) in (N.RT_OK, N.RT_ERR_NO_DEVICE)
+
+
+def test_group_inside_csg_gets_a_hierarchy_only_without_conics():
+    # a cylinder or cone can return a hit outside its box (primitive.rs:486-490); the direction index makes up for
+    # that for whole CSG nodes, not inside one
+    def wedges(with_cylinder):
+        kids = [Primitive.new_cube().with_transform(Matrix.translation(3.0 * i, 0, 0)) for i in range(9)]
+        if with_cylinder:
+            kids.append(Primitive.new_cylinder(Conic(-1.0, 1.0, True)))
+        return rt.Compound.new_group(kids)
+    for with_cylinder in (False, True):
+        csg = rt.Compound.new_csg(Operation.Intersection, Primitive.new_sphere(), wedges(with_cylinder))
+        flat = World([csg, Primitive.new_sphere().with_transform(Matrix.translation(0, 9, 0))], []).flatten()
+        d = flat.desc.contents
+        assert (d.groups[0].bvh_root >= 0) == (not with_cylinder)
+        assert create(flat.desc) in (N.RT_OK, N.RT_ERR_NO_DEVICE)
+    # ... and the library refuses tables that break the rule: graft the tree onto the group that holds the cylinder
+    ok = World([rt.Compound.new_csg(Operation.Intersection, Primitive.new_sphere(), wedges(False)),
+                Primitive.new_sphere().with_transform(Matrix.translation(0, 9, 0))], []).flatten()
+    d = ok.desc.contents
+    group = next(i for i in range(d.n_shapes) if (d.shapes[i].kind_flags & 0xff) == N.RT_GROUP)
+    victim = d.shapes[group + 1]
+    victim.kind_flags = (victim.kind_flags & ~0xff) | N.RT_CYLINDER
+    victim.param = 0
+    assert d.n_conics == 0
+    conic = (N.RtConic * 1)(N.RtConic(-1.0, 1.0))
+    d.conics, d.n_conics = conic, 1
+    assert create(ok.desc) == N.RT_ERR_INVALID_SCENE
