@@ -627,6 +627,16 @@ int rt_hip_scene_create(const RtSceneDesc* desc, RtScene** out) {
     rth::Arena arena;
     int rc = RT_OK;
     const size_t o_shapes = arena.add(desc->shapes, sizeof(RtShape) * desc->n_shapes);
+    {  // RT_FLAG_IDENTITY: primitives whose inverse transform is the identity matrix bit for bit (rt_trace.h: identity_ray)
+        static const double kIdentity[12] = {1.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0};
+        RtShape* mine = reinterpret_cast<RtShape*>(arena.host.data() + o_shapes);
+        const bool off = std::getenv("RT_HIP_NO_IDENTITY") != nullptr;  // test knob: every primitive reads its matrix
+        for (uint32_t i = 0; i < desc->n_shapes; ++i) {
+            mine[i].kind_flags &= ~RT_FLAG_IDENTITY;
+            if (!off && RT_KIND(mine[i].kind_flags) <= RT_SMOOTH_TRIANGLE && std::memcmp(mine[i].inv, kIdentity, sizeof kIdentity) == 0)
+                mine[i].kind_flags |= RT_FLAG_IDENTITY;
+        }
+    }
     const size_t o_conics = arena.add(desc->conics, sizeof(RtConic) * desc->n_conics);
     const size_t o_tris = arena.add(desc->triangles, sizeof(RtTriangle) * desc->n_triangles);
     const size_t o_groups = arena.add(desc->groups, sizeof(RtGroup) * desc->n_groups);
@@ -672,7 +682,11 @@ int rt_hip_scene_create(const RtSceneDesc* desc, RtScene** out) {
                      sizeof(RtTriangle) * desc->n_triangles;
         const bool may_fit = is_flat ? bytes <= RT_STAGE_MAX_BYTES && world_hits <= RT_LDS_LIST_CAP : bytes <= RT_STAGE_MAX_BYTES_COMPOUND;
         if (may_fit) {  // (large scenes do not pay for an image they will not use)
-            put(desc->shapes, sizeof(RtShape) * desc->n_shapes, &s->dev.stage_off[0]);
+            {  // (the library's copy: it carries RT_FLAG_IDENTITY)
+                const std::vector<unsigned char> mine(arena.host.begin() + (long)o_shapes,
+                                                      arena.host.begin() + (long)(o_shapes + sizeof(RtShape) * desc->n_shapes));
+                put(mine.data(), mine.size(), &s->dev.stage_off[0]);
+            }
             put(desc->conics, sizeof(RtConic) * desc->n_conics, &s->dev.stage_off[1]);
             put(desc->materials, sizeof(RtMaterial) * desc->n_materials, &s->dev.stage_off[2]);
             put(desc->patterns, sizeof(RtPattern) * desc->n_patterns, &s->dev.stage_off[3]);

@@ -252,11 +252,33 @@ RT_DEV void prim_intersect_rec(const double* __restrict__ inv, unsigned kf, cons
     }
 }
 
+// What transform_ray returns for the identity matrix (entries +1.0 and +0.0, as Matrix::inverse leaves them), bit for
+// bit, without reading the matrix: a point's component is ((1*x + 0*y) + 0*z) + 0 = x, and +0 for x = +-0 (the last term
+// is +0); a vector's has no last term, so a zero component keeps a minus sign exactly when all three products are -0,
+// i.e. when all three components carry one.  (The caller has checked that every component is finite: 0 * inf is NaN.)
+// An OBJ mesh is thousands of triangles with this transform (obj.rs: parse_file): the teapot's leaf tests read 72 bytes
+// of triangle instead of 96 of matrix and 72 of triangle.
+#define RT_FLAG_IDENTITY (1u << 16)  // kind_flags, set by the library in its own copy of the tables (rt_hip_scene_create)
+RT_DEV Ray identity_ray(const Ray& r) {
+    const bool all_neg = __builtin_signbit(r.d.x) && __builtin_signbit(r.d.y) && __builtin_signbit(r.d.z);
+    const double z = all_neg ? -0.0 : 0.0;
+    return Ray{v3(r.o.x + 0.0, r.o.y + 0.0, r.o.z + 0.0),
+               v3(r.d.x != 0.0 ? r.d.x : z, r.d.y != 0.0 ? r.d.y : z, r.d.z != 0.0 ? r.d.z : z)};
+}
+RT_DEV bool ray_is_finite(const Ray& r) {
+    const double sum = ((fabs(r.o.x) + fabs(r.o.y)) + (fabs(r.o.z) + fabs(r.d.x))) + (fabs(r.d.y) + fabs(r.d.z));
+    return sum < __builtin_inf();  // (an overflowing sum only sends the ray the long way round)
+}
+
 template <bool STATS, int FLAT>
 RT_DEV void prim_intersect(const SceneDev& S, const RtShape* __restrict__ sh, unsigned kf, const Ray& parent_ray,
                            PrimHits& h, Ctx<STATS, FLAT>& cx) {
     // shape.rs:28-32, ahead of the branches: lanes holding different kinds of primitive share it
-    const Ray r = transform_ray(sh->inv, parent_ray);
+    Ray r;
+    if ((kf & RT_FLAG_IDENTITY) && ray_is_finite(parent_ray))
+        r = identity_ray(parent_ray);
+    else
+        r = transform_ray(sh->inv, parent_ray);
     const unsigned kind = RT_KIND(kf);
     count(cx, ST_RAY_XFORM);
     count(cx, ST_PRIM0 + (int)kind);

@@ -151,6 +151,44 @@ def test_conic_parallel_ray_branch_under_acceleration():
     assert not rel_mismatch(col, ow.color_at(rays, 2)).any()
 
 
+def test_identity_transform_shortcut_is_bit_exact_down_to_the_sign_of_zero(monkeypatch):
+    """Primitives whose inverse transform is the identity matrix skip the ray transform (rt_trace.h: identity_ray).
+    1*x + 0*y + 0*z (+ 0) differs from x only in the sign of a zero, which the shortcut reproduces: every combination of
+    signed zeros and ordinary values in origin and direction, through every primitive kind, against the same scene with
+    the shortcut switched off -- compared as bit patterns -- and against the oracle."""
+    import itertools
+    from raytracer_amd import Conic, Material, Matrix, PointLight, Primitive, World
+
+    def build():
+        tri = [Primitive.new_triangle((-1, -1, 0.5), (1, -1, 0.5), (0, 1, 0.5)),
+               Primitive.new_smooth_triangle((-1, -1, -0.5), (1, -1, -0.5), (0, 1, -0.5), (0, 0, 1), (0, 1, 0), (1, 0, 0))]
+        solids = [Primitive.new_sphere().with_material(Material(color=(0.9, 0.2, 0.2), reflective=0.3)),
+                  Primitive.new_cube().with_material(Material(color=(0.2, 0.9, 0.2), transparency=0.5, refractive_index=1.3)),
+                  Primitive.new_cylinder(Conic(-0.7, 0.7, True))]  # (no cone: rays through its apex, the origin, have no normal)
+        group = rt.Compound.new_group(tri + [Primitive.new_plane()])
+        return World(solids + [group], [PointLight((-5, 8, -10), (1, 1, 1))])
+
+    vals_o = (-0.0, 0.0, -1.5, 0.7)
+    vals_d = (-0.0, 0.0, -1.0, 1.0, -0.3, 0.3)
+    rays = np.array([o + d for o in itertools.product(vals_o, repeat=3) for d in itertools.product(vals_d, repeat=3)
+                     if any(c != 0.0 for c in d)], dtype=np.float64)
+    assert len(rays) > 13000
+    world = build()
+    got_p, got_c = world.probe(rays), world.color_at(rays, 3)
+    monkeypatch.setenv("RT_HIP_NO_IDENTITY", "1")
+    plain = build()
+    ref_p, ref_c = plain.probe(rays), plain.color_at(rays, 3)
+    monkeypatch.delenv("RT_HIP_NO_IDENTITY")
+    same_p = (got_p.view(np.uint64) == ref_p.view(np.uint64)) | (np.isnan(got_p) & np.isnan(ref_p))
+    same_c = (got_c.view(np.uint64) == ref_c.view(np.uint64)) | (np.isnan(got_c) & np.isnan(ref_c))
+    assert same_p.all() and same_c.all()
+    ow = orc.OracleWorld(world.describe())
+    ref = ow.probe(rays)
+    ok = ~np.isnan(ref).any(axis=1)
+    assert np.array_equal(got_p[ok][:, [0, 2]], ref[ok][:, [0, 2]])
+    assert not rel_mismatch(got_p[ok], ref[ok], 1e-12, 1e-15).any()
+
+
 def test_direction_cells_built_on_the_device_equal_host_built_ones():
     """From 64 candidate conics on the flattener lists the candidates only and rt_hip_scene_create rasterises the
     direction cells on the device (rt_dirindex.hip).  Same frames as with the host-built table, in every mode; and the
