@@ -59,6 +59,7 @@ struct Wf2Accel {
     float seg_near;      // containers walk: how far behind the origin the segment walk starts (RT_HIP_WF2_SEG_NEAR: studies)
     const LeafPre* pre;  // by shape index; null: no f32 test ahead of the leaves (RT_HIP_WF2_PRE=0: studies)
     float extent_max;
+    uint32_t list_share;  // containers walks: chunks per resident wave a launch is cut into at least (RT_HIP_WF2_LIST_SHARE)
 };
 
 // ---- the f32 side of a ray: conservative slab tests ------------------------------------------------------------

@@ -214,6 +214,9 @@ __global__ __launch_bounds__(256) void wf2_cands_kernel(const SceneDev S, Wf2Spa
 #ifndef RT_WF2_PEND_COLOUR
 #define RT_WF2_PEND_COLOUR 0  // the same for colour rays (closest hit): every leaf can shorten the rest of their walk
 #endif
+#ifndef RT_WF2_LIST_SHARE
+#define RT_WF2_LIST_SHARE 1u
+#endif
 #ifndef RT_WF2_TRACE_WAVES
 #define RT_WF2_TRACE_WAVES 4  // waves per SIMD the traversal kernel is compiled for (<= 128 VGPRs)
 #endif
@@ -252,7 +255,9 @@ __global__ __launch_bounds__(64, RT_WF2_TRACE_WAVES) void wf2_trace_kernel(const
             total = 0;
             for (unsigned p = 0; p < RT_WF2_PARTS; ++p) total += sp.cnt->n_creq[p].v;
         }
-        while (chunk > RT_WF2_MIN_CHUNK && (unsigned long long)gridDim.x * chunk > total) chunk >>= 1;
+        // (LIST: A.list_share chunks per resident wave at least -- lines differ a lot in what they meet, and a wave lasts as
+        // long as its longest)
+        while (chunk > RT_WF2_MIN_CHUNK && (unsigned long long)gridDim.x * chunk * (LIST ? A.list_share : 1u) > total) chunk >>= 1;
     }
     const unsigned per_part = LIST ? sp.creq_part_cap : ((n + chunk - 1u) / chunk + RT_WF2_PARTS - 1u) / RT_WF2_PARTS * chunk;
     unsigned part = blockIdx.x % RT_WF2_PARTS, parts_left = RT_WF2_PARTS;
@@ -488,13 +493,19 @@ __global__ __launch_bounds__(64, RT_WF2_TRACE_WAVES) void wf2_trace_kernel(const
             w.sp = 1;
             w.cur = A.root_open;
         }
-        if (busy && w.cur == RT_BVH4_DONE && p_n == 0u) {
-            if constexpr (LIST) {
+        if constexpr (LIST) {
+            // the containers loop over a finished list: once per wave and chunk, when its last walk is through -- lane by
+            // lane as the walks end it ran with one or two lanes at a time and was a quarter of this kernel
+            const bool through = busy && w.cur == RT_BVH4_DONE && p_n == 0u;
+            if (__builtin_amdgcn_ballot_w64(busy && !through) == 0ull && through) {
                 double n1, n2;
                 if (!containers_in_registers(S, W, top, ctx_f(sp, slot, CX_T), n1, n2)) containers_from_list(S, W, top, ctx_f(sp, slot, CX_T), n1, n2);
                 ctx_f(sp, slot, CX_N1) = n1;
                 ctx_f(sp, slot, CX_N2) = n2;
-            } else if constexpr (SHADOW) {
+                busy = false;
+            }
+        } else if (busy && w.cur == RT_BVH4_DONE && p_n == 0u) {
+            if constexpr (SHADOW) {
                 sp.occ[item] = found ? 1 : 0;
             } else {
                 Wf2Hit h;

@@ -533,6 +533,7 @@ int rth::wf2_create(const RtSceneDesc& d, uint32_t scene_flags, Arena& arena, Wf
     };
     w->accel.chunk = env_or("RT_HIP_WF2_CHUNK", RT_WF2_CHUNK, 1u, 1u << 20);
     w->accel.refill = env_or("RT_HIP_WF2_REFILL", RT_WF2_REFILL, 1u, 64u);
+    w->accel.list_share = env_or("RT_HIP_WF2_LIST_SHARE", RT_WF2_LIST_SHARE, 1u, 64u);
     w->accel.slack = (1.0f / 1048576.0f) * (float)env_or("RT_HIP_WF2_SLACK", 1u, 1u, 1u << 20);
     w->accel.seg_near = env_or("RT_HIP_WF2_SEG_NEAR", 0u, 0u, 1u) ? -1e-2f : -INFINITY;
     w->n_nodes = (uint32_t)b.nodes.size();
