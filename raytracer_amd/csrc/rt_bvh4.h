@@ -370,16 +370,12 @@ RT_DEV int wf2_leaf_list(const SceneDev& S, LaneList& W, int top, int s, const R
     const RtShape* __restrict__ sh = S.shapes + s;
     const unsigned kf = sh->kind_flags;
     const int parent = anc0 == RT_PRE_DEEP ? sh->parent : -1;
+    // (the gates on the way down, not after the fact as wf2_leaf has them: nearly every hit on the line counts here, and the
+    // second way down costs more than the gates of the leaves that yield nothing)
     Ray at = world_ray;
-    leaf_way_down<false>(S, parent, anc0, anc1, at, cx);
+    if (!leaf_way_down<true>(S, parent, anc0, anc1, at, cx)) return top;
     PrimHits h;
     prim_intersect(S, sh, kf, at, h, cx);
-    bool useful = false;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) useful = useful || (((h.keep >> k) & 1u) && h.t[k] <= bound);
-    if (!useful) return top;
-    Ray r = world_ray;
-    if (!leaf_way_down<true>(S, parent, anc0, anc1, r, cx)) return top;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (((h.keep >> k) & 1u) && h.t[k] <= bound) {
