@@ -18,7 +18,12 @@ static_assert(sizeof(Bvh4Node) == 64, "one node = four 16-byte words: half the w
 #define RT_BVH4_LEAF 0x80000000u
 #define RT_BVH4_DONE 0x7fffffffu
 #define RT_BVH4_NOPRE 0x40000000u  // in a leaf code: the leaf has no f32 pre-test (planes, triangles): its record is read for the ancestors only
-#define RT_BVH4_SHAPE(code) ((code) & 0x3fffffffu)
+// ... and the class of its primitive's intersection code in bits 27-29 (0 sphere, 1 plane, 2 cube, 3 cylinder / cone,
+// 4 triangle): the traversal kernel picks the leaves a wave tests together by it
+#define RT_BVH4_CLASS_SHIFT 27
+#define RT_BVH4_CLASS(code) (((code) >> RT_BVH4_CLASS_SHIFT) & 7u)
+#define RT_BVH4_N_CLASSES 5
+#define RT_BVH4_SHAPE(code) ((code) & 0x07ffffffu)
 #ifndef RT_WF2_LDS_STACK
 #define RT_WF2_LDS_STACK 24   // stack entries per lane kept in LDS; deeper ones in private memory
 #endif

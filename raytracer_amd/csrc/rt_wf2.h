@@ -214,6 +214,9 @@ __global__ __launch_bounds__(256) void wf2_cands_kernel(const SceneDev S, Wf2Spa
 #ifndef RT_WF2_PEND_COLOUR
 #define RT_WF2_PEND_COLOUR 0  // the same for colour rays (closest hit): every leaf can shorten the rest of their walk
 #endif
+#ifndef RT_WF2_LEAF_CLASSES
+#define RT_WF2_LEAF_CLASSES 0  // study knob (measured, slower): 1 = a round of leaf tests takes the leaves of ONE class of primitive, the wave's commonest; 2 = every lane takes one, of that class if it has one
+#endif
 #ifndef RT_WF2_LIST_SHARE
 #define RT_WF2_LIST_SHARE 1u
 #endif
@@ -402,7 +405,7 @@ __global__ __launch_bounds__(64, RT_WF2_TRACE_WAVES) void wf2_trace_kernel(const
                 if (inner) {
                     walk_step(A, f, t_near, t_far, w, lds_stack, deep, cx);
                 } else if (busy && (w.cur & RT_BVH4_LEAF) && p_n < (unsigned)PEND) {
-                    pend[((p_head + p_n) % (unsigned)PEND) * 64u] = w.cur;
+                    pend[(RT_WF2_LEAF_CLASSES ? p_n : (p_head + p_n) % (unsigned)PEND) * 64u] = w.cur;
                     ++p_n;
                     walk_pop(w, lds_stack, deep);
                 }
@@ -431,7 +434,39 @@ __global__ __launch_bounds__(64, RT_WF2_TRACE_WAVES) void wf2_trace_kernel(const
         for (int pass = 0; pass < (SHADOW && RT_WF2_SHADOW_HINT ? 2 : 1); ++pass) {
             bool take, keep_walk;
             uint32_t leaf;
-            if (pass == 0) {
+            if (pass == 0 && PEND > 0 && RT_WF2_LEAF_CLASSES) {
+                // The leaves set aside are a bag, not a queue: of all the wave holds, this round tests those of ONE class of
+                // primitive -- the one most lanes have -- so that the intersection code below runs one branch with many
+                // lanes instead of five with a few each (the order in which a feeler or a containers walk meets its leaves
+                // changes nothing).  The leaf at hand joins the bag first when there is room.
+                if (busy && (w.cur & RT_BVH4_LEAF) && p_n < (unsigned)PEND) {
+                    pend[p_n * 64u] = w.cur;
+                    ++p_n;
+                    walk_pop(w, lds_stack, deep);
+                }
+                unsigned mask = 0u;
+#pragma unroll
+                for (unsigned k = 0; k < (unsigned)(PEND > 0 ? PEND : 1); ++k)
+                    if (busy && k < p_n) mask |= 1u << RT_BVH4_CLASS(pend[k * 64u]);
+                int cls = -1, most = 0;
+#pragma unroll
+                for (int c = 0; c < RT_BVH4_N_CLASSES; ++c) {
+                    const int n_c = __builtin_popcountll(__builtin_amdgcn_ballot_w64(((mask >> c) & 1u) != 0u));
+                    if (n_c > most) most = n_c, cls = c;
+                }
+                take = RT_WF2_LEAF_CLASSES == 2 ? mask != 0u : (cls >= 0 && ((mask >> (cls >= 0 ? cls : 0)) & 1u) != 0u);
+                keep_walk = true;
+                leaf = RT_BVH4_DONE;
+                if (take) {
+                    unsigned at = 0u;  // (2: every lane takes a leaf, of the wave's commonest class if it has one)
+#pragma unroll
+                    for (unsigned k = (unsigned)(PEND > 0 ? PEND : 1); k-- > 0u;)
+                        if (k < p_n && RT_BVH4_CLASS(pend[k * 64u]) == (unsigned)cls) at = k;
+                    leaf = pend[at * 64u];
+                    --p_n;
+                    if (at != p_n) pend[at * 64u] = pend[p_n * 64u];
+                }
+            } else if (pass == 0) {
                 const bool from_ring = PEND > 0 && busy && p_n != 0u;
                 take = from_ring || (busy && (w.cur & RT_BVH4_LEAF));
                 keep_walk = from_ring;

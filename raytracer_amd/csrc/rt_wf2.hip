@@ -426,7 +426,7 @@ int rth::wf2_create(const RtSceneDesc& d, uint32_t scene_flags, Arena& arena, Wf
     // What the pipeline covers: a world-level hierarchy whose leaves are primitives (nested in groups or not), no CSG
     // node and no shadowless primitive anywhere (those need the sorted world list per ray: the older kernels have it).
     if (d.world_bvh_root < 0 || (scene_flags & RT_SCENE_HAS_SHADOWLESS) || d.n_csgs != 0 || d.n_lights == 0) return RT_OK;
-    if (d.n_shapes >= RT_BVH4_NOPRE) return RT_OK;  // (a leaf code keeps its top two bits for flags)
+    if (d.n_shapes >= (1u << RT_BVH4_CLASS_SHIFT)) return RT_OK;  // (a leaf code keeps its top five bits for flags and the class)
     std::vector<TNode> tree;
     std::vector<uint32_t> top;
     if (!parse_seq(d, d.world_bvh_root, -1, tree, top, 0) || top.empty()) return RT_OK;
@@ -518,7 +518,13 @@ int rth::wf2_create(const RtSceneDesc& d, uint32_t scene_flags, Arena& arena, Wf
         }
     {  // leaves without a pre-test say so in their code (the walk then reads two of the record's five words)
         auto flag = [&](uint32_t code) {
-            if ((code & RT_BVH4_LEAF) && code != RT_BVH4_DONE && pre[RT_BVH4_SHAPE(code)].kind == RT_PRE_NONE) code |= RT_BVH4_NOPRE;
+            if ((code & RT_BVH4_LEAF) && code != RT_BVH4_DONE) {
+                const uint32_t shape = RT_BVH4_SHAPE(code);
+                if (pre[shape].kind == RT_PRE_NONE) code |= RT_BVH4_NOPRE;
+                const unsigned kind = RT_KIND(d.shapes[shape].kind_flags);
+                const uint32_t cls = kind == RT_SPHERE ? 0u : (kind == RT_PLANE ? 1u : (kind == RT_CUBE ? 2u : (kind == RT_CYLINDER || kind == RT_CONE ? 3u : 4u)));
+                code |= cls << RT_BVH4_CLASS_SHIFT;
+            }
             return code;
         };
         for (Bvh4Node& nd : b.nodes)
