@@ -13,6 +13,10 @@
 using namespace rtd;
 using namespace rtk;
 
+#ifndef RT_WF2_SIDE_BLOCKS
+#define RT_WF2_SIDE_BLOCKS 0  // feelers on the second stream: one-wave blocks per CU (0: as many as fit; RT_HIP_WF2_SIDE_BLOCKS)
+#endif
+
 struct Wf2 {
     size_t off_nodes = 0, off_pre = 0, off_accel = 0;  // the hierarchy, the leaf records and the accel record inside the scene's block of tables
     bool has_pre = false;
@@ -24,6 +28,7 @@ struct Wf2 {
     size_t batch_pixels = 0, q_items = 0, node_items = 0;
     int trace_blocks_per_cu[2][4] = {};  // [stats][mode], from the occupancy query
     int n_cus = 0;
+    int side_blocks = 0;  // feelers on the second stream: one-wave blocks per CU (0: as many as fit)
     // a generation's containers walks run beside its feelers (neither reads what the other writes): a stream of the
     // scene's own, forked from and joined to the caller's by these events (created with the scene: a launch creates nothing)
     hipStream_t side = nullptr;
@@ -578,6 +583,8 @@ int rth::wf2_create(const RtSceneDesc& d, uint32_t scene_flags, Arena& arena, Wf
             pd.known = true;
         }
         w->n_cus = pd.n_cus;
+        if (const char* e = std::getenv("RT_HIP_WF2_SIDE_BLOCKS")) w->side_blocks = std::atoi(e);
+        else w->side_blocks = RT_WF2_SIDE_BLOCKS;
         std::memcpy(w->trace_blocks_per_cu, pd.blocks, sizeof pd.blocks);
         const char* side_env = std::getenv("RT_HIP_WF2_SIDE");
         if (!(side_env && *side_env == '0')) {
@@ -629,8 +636,13 @@ int run_pipeline(const RtScene* scene, const Wf2* w, const Wf2Space& sp, size_t 
     const dim3 wide(2048), threads(256);
     auto go = [&](auto stats_tag) {
         constexpr bool ST = decltype(stats_tag)::value;
-        const dim3 tgrid[4] = {dim3((unsigned)(w->n_cus * w->trace_blocks_per_cu[ST][0])), dim3((unsigned)(w->n_cus * w->trace_blocks_per_cu[ST][1])),
-                               dim3((unsigned)(w->n_cus * w->trace_blocks_per_cu[ST][2])), dim3((unsigned)(w->n_cus * w->trace_blocks_per_cu[ST][3]))};
+        dim3 tgrid[4] = {dim3((unsigned)(w->n_cus * w->trace_blocks_per_cu[ST][0])), dim3((unsigned)(w->n_cus * w->trace_blocks_per_cu[ST][1])),
+                         dim3((unsigned)(w->n_cus * w->trace_blocks_per_cu[ST][2])), dim3((unsigned)(w->n_cus * w->trace_blocks_per_cu[ST][3]))};
+        // The feelers' waves are persistent and at 128 VGPRs four of them fill a SIMD's register file: with every slot taken,
+        // whatever the caller's stream launches next waits for feelers to run dry.  On two streams they take `side_blocks` of
+        // the slots per CU and leave the rest to the critical path.
+        if (w->side != nullptr && w->side_blocks > 0 && w->side_blocks < w->trace_blocks_per_cu[ST][2])
+            tgrid[2] = dim3((unsigned)(w->n_cus * w->side_blocks));
         // children of a stretch of 2^shift consecutive hits share a shard (picked by a hash of the stretch): large enough to
         // keep neighbours together, small enough that every shard gets MANY stretches -- a shard's slice of the queue holds
         // 1.5 x its fair share, and with 8 stretches per shard (a 1/8 share of a 4K frame under the old rule) the hash left
