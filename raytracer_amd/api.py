@@ -414,9 +414,9 @@ class DeviceScene:
         self._p = p
 
     def close(self):
-        if self._p:
+        if self._p and N is not None and getattr(N, "hip", None) is not None:  # (module globals are gone at interpreter exit)
             N.hip.rt_hip_scene_destroy(self._p)
-            self._p = None
+        self._p = None
 
     def __del__(self):
         self.close()

@@ -22,4 +22,5 @@ for n in (1, 2, 4, 8):
         scene.render_rows(cd, 5, 0, n, 16, rows, buf.data_ptr(), stream)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t) / k * 1e3
-    print(f"N={n}: part 0 has {rows} rows, {ms:.2f} ms per frame share; ideal {20.2 / n:.2f}", flush=True)
+    whole = ms if n == 1 else whole
+    print(f"N={n}: part 0 has {rows} rows, {ms:.2f} ms per frame share; an even split of N=1's time {whole / n:.2f}", flush=True)
