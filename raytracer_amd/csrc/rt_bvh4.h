@@ -72,7 +72,7 @@ struct Wf2Accel {
 // K = |inv| * 2^-20 * (|o| + extent): every rounding of the f32 evaluation (o and inv rounded to f32, the product-sum,
 // and a relative 2^-23 of t, whose spatial size along the axis is bounded by |o| + extent) moves a plane by less.
 struct RayF32 {
-    float inv[3], cl[3], ch[3];
+    float inv[3], cn[3], cf[3];  // slope; the constant of the plane met first (shifted down), of the one met second (shifted up)
 };
 RT_DEV float f32_up(double x) { return __double2float_ru(x); }
 RT_DEV float f32_down(double x) { return __double2float_rd(x); }
@@ -88,9 +88,10 @@ RT_DEV void ray_f32(const Ray& r, const float extent[3], float slack, RayF32& f)
         const double c = -o[a] * (double)invf;
         const double k = fabs((double)invf) * (double)slack * (fabs(o[a]) + (double)extent[a]);
         f.inv[a] = invf;
-        // the plane met first is lo when the slope is positive, hi when it is negative; first planes move down, second up
-        f.cl[a] = invf >= 0.f ? f32_down(c - k) : f32_up(c + k);
-        f.ch[a] = invf >= 0.f ? f32_up(c + k) : f32_down(c - k);
+        // the plane met first is lo when the slope is positive, hi when it is negative (walk_step picks by the slope's
+        // sign); first planes move down, second up
+        f.cn[a] = f32_down(c - k);
+        f.cf[a] = f32_up(c + k);
     }
 }
 
@@ -112,26 +113,34 @@ RT_DEV void walk_step(const Wf2Accel& A, const RayF32& f, float t_near, float t_
     const uint32_t kid[4] = {w1.x, w1.y, w1.z, w1.w};
     const uint32_t qlo[3] = {w2.x, w2.y, w2.z}, qhi[3] = {w2.w, w3.x, w3.y};
     // plane(axis, child) = org + q * step, so t = q * (step * inv) + (org * inv + c): the slack in c (ray_f32) also covers
-    // the one extra rounding of org * inv + c
-    float sinv[3], cl[3], ch[3];
+    // the one extra rounding of org * inv + c.  Which of an axis' two planes the ray meets first is the sign of its slope:
+    // the four children's lo or hi bytes are picked as one word per axis, and entry / exit are a max3 / min3 of products --
+    // no per-child min / max of the two planes; the twelve products per side go two to an instruction (v_pk_fma_f32).
+    typedef float f2 __attribute__((ext_vector_type(2)));
     const float org[3] = {__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z)};
+    f2 n01[3], n23[3], f01[3], f23[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         const float step = __uint_as_float(((w0.w >> (8 * a)) & 0xffu) << 23);
-        sinv[a] = step * f.inv[a];
-        cl[a] = __builtin_fmaf(org[a], f.inv[a], f.cl[a]);
-        ch[a] = __builtin_fmaf(org[a], f.inv[a], f.ch[a]);
+        const float sinv = step * f.inv[a];
+        const float cn = __builtin_fmaf(org[a], f.inv[a], f.cn[a]), cf = __builtin_fmaf(org[a], f.inv[a], f.cf[a]);
+        const bool neg = f.inv[a] < 0.f;
+        const uint32_t qn = neg ? qhi[a] : qlo[a], qf = neg ? qlo[a] : qhi[a];
+        const f2 s2 = {sinv, sinv}, cn2 = {cn, cn}, cf2 = {cf, cf};
+        const f2 bn01 = {(float)(qn & 0xffu), (float)((qn >> 8) & 0xffu)}, bn23 = {(float)((qn >> 16) & 0xffu), (float)(qn >> 24)};
+        const f2 bf01 = {(float)(qf & 0xffu), (float)((qf >> 8) & 0xffu)}, bf23 = {(float)((qf >> 16) & 0xffu), (float)(qf >> 24)};
+        n01[a] = __builtin_elementwise_fma(bn01, s2, cn2), n23[a] = __builtin_elementwise_fma(bn23, s2, cn2);
+        f01[a] = __builtin_elementwise_fma(bf01, s2, cf2), f23[a] = __builtin_elementwise_fma(bf23, s2, cf2);
     }
     uint32_t next = RT_BVH4_DONE;
     float t_next = __builtin_inff();
     bool have = false;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const float ax = __builtin_fmaf((float)((qlo[0] >> (8 * c)) & 0xffu), sinv[0], cl[0]), bx = __builtin_fmaf((float)((qhi[0] >> (8 * c)) & 0xffu), sinv[0], ch[0]);
-        const float ay = __builtin_fmaf((float)((qlo[1] >> (8 * c)) & 0xffu), sinv[1], cl[1]), by = __builtin_fmaf((float)((qhi[1] >> (8 * c)) & 0xffu), sinv[1], ch[1]);
-        const float az = __builtin_fmaf((float)((qlo[2] >> (8 * c)) & 0xffu), sinv[2], cl[2]), bz = __builtin_fmaf((float)((qhi[2] >> (8 * c)) & 0xffu), sinv[2], ch[2]);
-        const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
-        const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+        const float nx = c < 2 ? n01[0][c & 1] : n23[0][c & 1], ny = c < 2 ? n01[1][c & 1] : n23[1][c & 1], nz = c < 2 ? n01[2][c & 1] : n23[2][c & 1];
+        const float fx = c < 2 ? f01[0][c & 1] : f23[0][c & 1], fy = c < 2 ? f01[1][c & 1] : f23[1][c & 1], fz = c < 2 ? f01[2][c & 1] : f23[2][c & 1];
+        const float tn = fmaxf(fmaxf(nx, ny), nz);
+        const float tf = fminf(fminf(fx, fy), fz);
         // (negated comparisons: a NaN anywhere lets the box through, as the f64 walk does)
         const bool met = kid[c] != RT_BVH4_DONE && !(tn > tf) && !(tf < t_near) && !(tn > t_far);
         if (met) {
