@@ -167,7 +167,10 @@ struct BvhItem {
 
 // Skip-link layout in depth-first order: node i's subtree is [i, miss); a walk goes to i+1 on
 // a box hit and to `miss` on a miss or after a leaf.  Binned surface-area split.
-void build_bvh_range(std::vector<BvhItem>& items, size_t lo, size_t hi, int32_t after, std::vector<RtBvhNode>& nodes) {
+// The subtree of n items occupies nodes[self, self + 2n - 1): the two halves of a split write disjoint ranges of `items`
+// and `nodes`, so the upper `par_depth` levels of a large tree hand their left halves to threads of their own (the tree is
+// the same whatever the number of threads).
+void build_bvh_range(std::vector<BvhItem>& items, size_t lo, size_t hi, int32_t after, RtBvhNode* nodes, size_t self, int par_depth) {
     const size_t n = hi - lo;
     ABox all, cent;
     for (size_t i = lo; i < hi; ++i) {
@@ -179,7 +182,7 @@ void build_bvh_range(std::vector<BvhItem>& items, size_t lo, size_t hi, int32_t 
     node.miss = after;
     if (n == 1) {
         node.shape = static_cast<int32_t>(items[lo].shape);
-        nodes.push_back(node);
+        nodes[self] = node;
         return;
     }
     node.shape = -1;
@@ -240,12 +243,18 @@ void build_bvh_range(std::vector<BvhItem>& items, size_t lo, size_t hi, int32_t 
         std::sort(first, last, [](const BvhItem& x, const BvhItem& y) { return x.shape < y.shape; });
         best_mid = lo + n / 2;
     }
-    const size_t self = nodes.size();
-    nodes.push_back(node);
+    nodes[self] = node;
     const size_t n_left = best_mid - lo;
-    const int32_t right_root = static_cast<int32_t>(self + 1 + (2 * n_left - 1));
-    build_bvh_range(items, lo, best_mid, right_root, nodes);
-    build_bvh_range(items, best_mid, hi, after, nodes);
+    const size_t right_self = self + 1 + (2 * n_left - 1);
+    const int32_t right_root = static_cast<int32_t>(right_self);
+    if (par_depth > 0 && n >= 2048) {
+        std::thread left([&] { build_bvh_range(items, lo, best_mid, right_root, nodes, self + 1, par_depth - 1); });
+        build_bvh_range(items, best_mid, hi, after, nodes, right_self, par_depth - 1);
+        left.join();
+    } else {
+        build_bvh_range(items, lo, best_mid, right_root, nodes, self + 1, 0);
+        build_bvh_range(items, best_mid, hi, after, nodes, right_self, 0);
+    }
 }
 
 // Returns the root index, or -1 when nothing was built.
@@ -260,8 +269,13 @@ int32_t build_bvh(std::vector<BvhItem> items, std::vector<RtBvhNode>& nodes) {
     const int32_t root = static_cast<int32_t>(nodes.size());
     const size_t tree_nodes = bounded.empty() ? 0 : 2 * bounded.size() - 1;
     const int32_t first_unbounded = static_cast<int32_t>(nodes.size() + tree_nodes);
-    if (!bounded.empty())
-        build_bvh_range(bounded, 0, bounded.size(), unbounded.empty() ? -1 : first_unbounded, nodes);
+    if (!bounded.empty()) {
+        nodes.resize(nodes.size() + tree_nodes);
+        unsigned hw = std::thread::hardware_concurrency();
+        int par_depth = hw >= 8 ? 3 : (hw >= 4 ? 2 : (hw >= 2 ? 1 : 0));
+        if (const char* e = std::getenv("RT_FLATTEN_THREADS")) par_depth = std::atoi(e) <= 1 ? 0 : par_depth;  // study knob
+        build_bvh_range(bounded, 0, bounded.size(), unbounded.empty() ? -1 : first_unbounded, nodes.data(), static_cast<size_t>(root), par_depth);
+    }
     for (size_t k = 0; k < unbounded.size(); ++k) {  // always-visited leaves after the tree
         RtBvhNode leaf;
         for (int a = 0; a < 3; ++a) leaf.bmin[a] = -INFINITY, leaf.bmax[a] = INFINITY;

@@ -291,3 +291,17 @@ def test_group_inside_csg_gets_a_hierarchy_only_without_conics():
     conic = (N.RtConic * 1)(N.RtConic(-1.0, 1.0))
     d.conics, d.n_conics = conic, 1
     assert create(ok.desc) == N.RT_ERR_INVALID_SCENE
+
+
+def test_hierarchy_does_not_depend_on_the_builder_threads(monkeypatch):
+    # the upper levels of a large hierarchy are built by threads of their own (disjoint ranges of items and nodes)
+    world, _ = rt.synthetic(64, 36, 6000)
+    fa = world.flatten()
+    a = fa.desc.contents
+    assert a.n_bvh_nodes > 8000
+    nodes_a = C.string_at(a.bvh_nodes, a.n_bvh_nodes * C.sizeof(a.bvh_nodes._type_))
+    monkeypatch.setenv("RT_FLATTEN_THREADS", "1")
+    fb = world.flatten()
+    b = fb.desc.contents
+    assert b.n_bvh_nodes == a.n_bvh_nodes and b.world_bvh_root == a.world_bvh_root
+    assert C.string_at(b.bvh_nodes, b.n_bvh_nodes * C.sizeof(b.bvh_nodes._type_)) == nodes_a
