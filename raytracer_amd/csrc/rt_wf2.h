@@ -260,7 +260,13 @@ __global__ __launch_bounds__(64, RT_WF2_TRACE_WAVES) void wf2_trace_kernel(const
         }
         // (LIST: A.list_share chunks per resident wave at least -- lines differ a lot in what they meet, and a wave lasts as
         // long as its longest)
-        while (chunk > RT_WF2_MIN_CHUNK && (unsigned long long)gridDim.x * chunk * (LIST ? A.list_share : 1u) > total) chunk >>= 1;
+        // With fewer rays than that: ONE chunk per wave, as even as it comes (any size, not a power of two) -- a wave that
+        // takes two chunks of 16 one after the other lasts twice as long as one that takes its 25 at once.
+        const unsigned long long slots = (unsigned long long)gridDim.x * (LIST ? A.list_share : 1u);
+        if (slots * chunk > total) {
+            const unsigned even = (unsigned)((total + slots - 1u) / slots);
+            chunk = even < RT_WF2_MIN_CHUNK ? RT_WF2_MIN_CHUNK : (even < chunk ? even : chunk);
+        }
     }
     const unsigned per_part = LIST ? sp.creq_part_cap : ((n + chunk - 1u) / chunk + RT_WF2_PARTS - 1u) / RT_WF2_PARTS * chunk;
     unsigned part = blockIdx.x % RT_WF2_PARTS, parts_left = RT_WF2_PARTS;
