@@ -308,15 +308,28 @@ struct LaneList {
 // the first entry that is its object's last one before j* and whose object has an odd count there.
 //   n1 = last before the hit entry is processed (1.0 if none); the hit's object is then removed (odd count) or pushed
 //   (even); n2 = last after that.
-RT_DEV bool containers_in_registers(const SceneDev& S, LaneList& W, int n, double hit_t, double& n1, double& n2) {
-    uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-    int nc = 0;
-    n1 = 1.0, n2 = 1.0;
+// The loop's state, so that it can run over a list that comes in pieces (a line walked by several lanes, each holding the
+// entries of its own range of the ray parameter: see wf2_trace_kernel): phase 0 = still looking for the hit entry,
+// 1 = past it (n1, n2 final), 2 = a fifth object would have to be pushed (the list-only form has to answer).
+struct ContainersState {
+    uint32_t c0, c1, c2, c3;
+    int nc, phase;
+    double n1, n2;
+};
+RT_DEV void containers_begin(ContainersState& st) {
+    st.c0 = st.c1 = st.c2 = st.c3 = 0u;
+    st.nc = 0, st.phase = 0;
+    st.n1 = 1.0, st.n2 = 1.0;
+}
+RT_DEV void containers_run(const SceneDev& S, LaneList& W, int n, double hit_t, ContainersState& st) {
+    if (st.phase != 0) return;
+    uint32_t c0 = st.c0, c1 = st.c1, c2 = st.c2, c3 = st.c3;
+    int nc = st.nc;
     auto last = [&]() { return nc == 1 ? c0 : (nc == 2 ? c1 : (nc == 3 ? c2 : c3)); };
     for (int j = 0; j < n; ++j) {
         const bool is_self = t_eq(W.LT(j), hit_t);
         const uint32_t id = W.LID(j);
-        if (is_self && nc > 0) n1 = S.mats[S.shapes[last()].material].refractive_index;
+        if (is_self && nc > 0) st.n1 = S.mats[S.shapes[last()].material].refractive_index;
         const int pos = (nc > 0 && c0 == id) ? 0 : ((nc > 1 && c1 == id) ? 1 : ((nc > 2 && c2 == id) ? 2 : ((nc > 3 && c3 == id) ? 3 : -1)));
         if (pos >= 0) {  // remove: the later ones move up
             if (pos <= 0) c0 = c1;
@@ -324,7 +337,10 @@ RT_DEV bool containers_in_registers(const SceneDev& S, LaneList& W, int n, doubl
             if (pos <= 2) c2 = c3;
             --nc;
         } else {
-            if (nc == 4) return false;
+            if (nc == 4) {
+                st.phase = 2;
+                return;
+            }
             if (nc == 0) c0 = id;
             else if (nc == 1) c1 = id;
             else if (nc == 2) c2 = id;
@@ -332,11 +348,19 @@ RT_DEV bool containers_in_registers(const SceneDev& S, LaneList& W, int n, doubl
             ++nc;
         }
         if (is_self) {
-            if (nc > 0) n2 = S.mats[S.shapes[last()].material].refractive_index;
+            if (nc > 0) st.n2 = S.mats[S.shapes[last()].material].refractive_index;
+            st.phase = 1;
             break;
         }
     }
-    return true;
+    st.c0 = c0, st.c1 = c1, st.c2 = c2, st.c3 = c3, st.nc = nc;
+}
+RT_DEV bool containers_in_registers(const SceneDev& S, LaneList& W, int n, double hit_t, double& n1, double& n2) {
+    ContainersState st;
+    containers_begin(st);
+    containers_run(S, W, n, hit_t, st);
+    n1 = st.n1, n2 = st.n2;
+    return st.phase != 2;
 }
 RT_DEV void containers_from_list(const SceneDev& S, LaneList& W, int n, double hit_t, double& n1, double& n2) {
     n1 = 1.0, n2 = 1.0;
@@ -379,8 +403,10 @@ RT_DEV void containers_from_list(const SceneDev& S, LaneList& W, int n, double h
 // wf2_leaf for World::intersections as a sorted list cut at t <= bound (world_list): the primitive's surviving hits are
 // inserted with BTreeSet::append's tie rule.  Returns the new length.
 template <bool STATS, int FLAT>
+// (keep_lo <= t < keep_hi: the range of the ray parameter whose entries this lane keeps, when a line is shared out among lanes)
 RT_DEV int wf2_leaf_list(const SceneDev& S, LaneList& W, int top, int s, const Ray& world_ray, double bound, Ctx<STATS, FLAT>& cx,
-                         uint32_t anc0 = RT_PRE_DEEP, uint32_t anc1 = RT_PRE_NO_ANC) {
+                         uint32_t anc0 = RT_PRE_DEEP, uint32_t anc1 = RT_PRE_NO_ANC, double keep_lo = -__builtin_inf(),
+                         double keep_hi = __builtin_inf()) {
     const RtShape* __restrict__ sh = S.shapes + s;
     const unsigned kf = sh->kind_flags;
     const int parent = anc0 == RT_PRE_DEEP ? sh->parent : -1;
@@ -392,7 +418,7 @@ RT_DEV int wf2_leaf_list(const SceneDev& S, LaneList& W, int top, int s, const R
     prim_intersect(S, sh, kf, at, h, cx);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        if (((h.keep >> k) & 1u) && h.t[k] <= bound) {
+        if (((h.keep >> k) & 1u) && h.t[k] <= bound && h.t[k] >= keep_lo && h.t[k] < keep_hi) {
             top = list_insert(W, 0, top, h.t[k], (uint32_t)s, cx.status);
             count(cx, ST_LIST_ENTRIES);
         }

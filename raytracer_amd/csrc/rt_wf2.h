@@ -214,6 +214,9 @@ __global__ __launch_bounds__(256) void wf2_cands_kernel(const SceneDev S, Wf2Spa
 #ifndef RT_WF2_PEND_COLOUR
 #define RT_WF2_PEND_COLOUR 0  // the same for colour rays (closest hit): every leaf can shorten the rest of their walk
 #endif
+#ifndef RT_WF2_LIST_SPLIT
+#define RT_WF2_LIST_SPLIT 8u  // containers walks of small launches: lanes a line is shared out among at most (0: never)
+#endif
 #ifndef RT_WF2_LEAF_CLASSES
 #define RT_WF2_LEAF_CLASSES 0  // study knob (measured, slower): 1 = a round of leaf tests takes the leaves of ONE class of primitive, the wave's commonest; 2 = every lane takes one, of that class if it has one
 #endif
@@ -268,6 +271,21 @@ __global__ __launch_bounds__(64, RT_WF2_TRACE_WAVES) void wf2_trace_kernel(const
             chunk = even < RT_WF2_MIN_CHUNK ? RT_WF2_MIN_CHUNK : (even < chunk ? even : chunk);
         }
     }
+    // LIST, small launches: a line is shared out among `split` neighbouring lanes by ranges of the ray parameter.  A launch
+    // lasts as long as its slowest ray, a containers walk goes through everything its whole line meets, and with fewer rays
+    // than lanes the other lanes have nothing to do: lane k of a ray's `split` walks the k-th stretch of the line inside the
+    // scene's extent (the first also everything before it, the last everything after) and keeps the entries whose t falls
+    // into its own half-open range -- every entry ends up in exactly one lane, each lane's list is sorted, and the lists
+    // one after the other ARE the sorted list (equal t's share a range).  The containers loop then runs through them in
+    // order, its state handed from lane to lane.
+    unsigned split = 1u;
+#if RT_WF2_LIST_SPLIT
+    if constexpr (LIST) {
+        if (A.refill == 64u && !(A.seg_near > -__builtin_inff()))
+            while (split < RT_WF2_LIST_SPLIT && chunk * split * 2u <= 64u) split *= 2u;
+    }
+#endif
+    double keep_lo = -__builtin_inf(), keep_hi = __builtin_inf();
     const unsigned per_part = LIST ? sp.creq_part_cap : ((n + chunk - 1u) / chunk + RT_WF2_PARTS - 1u) / RT_WF2_PARTS * chunk;
     unsigned part = blockIdx.x % RT_WF2_PARTS, parts_left = RT_WF2_PARTS;
     unsigned part_lo = part * per_part;
@@ -321,7 +339,8 @@ __global__ __launch_bounds__(64, RT_WF2_TRACE_WAVES) void wf2_trace_kernel(const
             }
             const unsigned avail = chunk_end - chunk_next;
             if (avail != 0u) {
-                const unsigned rank = (unsigned)__builtin_popcountll(idle & below);
+                // (split > 1: the whole wave refills at once, `split` neighbouring lanes take one ray)
+                const unsigned rank = (unsigned)__builtin_popcountll(idle & below) / (LIST ? split : 1u);
                 if (!busy && rank < avail) {
                     item = chunk_next + rank;
                     busy = true;
@@ -334,9 +353,28 @@ __global__ __launch_bounds__(64, RT_WF2_TRACE_WAVES) void wf2_trace_kernel(const
                         const unsigned of = ctx_u(sp, slot, CU_ITEM);
                         valid = gen == 0u ? wf2_item_ray<WF2_PRIMARY>(S, sp, cam, rows, pm, of, 0u, ray, limit)
                                           : wf2_item_ray<WF2_QUEUE>(S, sp, cam, rows, pm, of, 0u, ray, limit);
-                        count(cx, ST_CONTAINER_PASSES);
+                        const unsigned sub = lane & (split - 1u);
+                        if (sub == 0u) count(cx, ST_CONTAINER_PASSES);
                         limit = containers_bound(ctx_f(sp, slot, CX_T));  // the list is cut here
                         top = 0;
+                        keep_lo = -__builtin_inf(), keep_hi = __builtin_inf();
+                        if (split > 1u) {
+                            // the stretch [a, b] of the line inside the scene's extent, cut at the list's bound, in `split` parts
+                            double a = -__builtin_inf(), b = limit;
+                            const double o3[3] = {ray.o.x, ray.o.y, ray.o.z}, d3[3] = {ray.d.x, ray.d.y, ray.d.z};
+#pragma unroll
+                            for (int ax = 0; ax < 3; ++ax) {
+                                const double e = (double)A.extent[ax] * 1.0001 + 1e-9;
+                                if (d3[ax] != 0.0) {
+                                    const double t1 = (-e - o3[ax]) / d3[ax], t2 = (e - o3[ax]) / d3[ax];
+                                    a = fmax(a, fmin(t1, t2)), b = fmin(b, fmax(t1, t2));
+                                }
+                            }
+                            if (!(a < b) || !(b - a < 1e300)) a = b = 0.0;  // (off the scene, or nothing to go by: the first and the last lane share the line)
+                            const double step = (b - a) / (double)split;
+                            if (sub != 0u) keep_lo = a + step * (double)sub;
+                            if (sub != split - 1u) keep_hi = a + step * (double)(sub + 1u);
+                        }
                         if (A.has_cands) {  // the direction index's candidates first, as world_list has them
                             CandIter it;
                             cand_begin(S, ray, it);
@@ -346,7 +384,7 @@ __global__ __launch_bounds__(64, RT_WF2_TRACE_WAVES) void wf2_trace_kernel(const
                                 ++it.k;
                                 const double a = c->q[0] * d.x * d.x + c->q[1] * d.y * d.y + c->q[2] * d.z * d.z +
                                                  2.0 * (c->q[3] * d.x * d.y + c->q[4] * d.x * d.z + c->q[5] * d.y * d.z);
-                                if (fabs(a) <= c->thr) top = wf2_leaf_list(S, W, top, (int)c->visit, ray, limit, cx);
+                                if (fabs(a) <= c->thr) top = wf2_leaf_list(S, W, top, (int)c->visit, ray, limit, cx, RT_PRE_DEEP, RT_PRE_NO_ANC, keep_lo, keep_hi);
                             }
                         }
                     } else {
@@ -372,6 +410,10 @@ __global__ __launch_bounds__(64, RT_WF2_TRACE_WAVES) void wf2_trace_kernel(const
                     // the header of this file for why that is not the default.)
                     t_near = LIST ? A.seg_near : 0.f;
                     second_walk = LIST && A.seg_near > -__builtin_inff();
+                    if constexpr (LIST) {  // (a lane's share of the line, rounded outwards)
+                        if (keep_lo > -__builtin_inf()) t_near = f32_down(keep_lo);
+                        if (keep_hi < __builtin_inf()) t_far = fminf(t_far, f32_up(keep_hi));
+                    }
                     // the stack: the sentinel, the hierarchy's root, the unbounded leaves -- those are tested first (a plane's
                     // hit bounds the walk), through the same leaf code as every other leaf
                     lds_stack[0] = RT_BVH4_DONE;
@@ -388,7 +430,10 @@ __global__ __launch_bounds__(64, RT_WF2_TRACE_WAVES) void wf2_trace_kernel(const
                     // (reflected / refracted rays are counted where they are queued, as in wf_level_kernel)
                     if (valid && (MODE == WF2_PRIMARY || SHADOW)) count(cx, SHADOW ? ST_RAY_SHADOW : ST_RAY_PRIMARY);
                 }
-                chunk_next += (unsigned)n_idle < avail ? (unsigned)n_idle : avail;
+                {
+                    const unsigned takers = (unsigned)n_idle / (LIST ? split : 1u);
+                    chunk_next += takers < avail ? takers : avail;
+                }
             } else if (n_idle == 64) {
                 break;  // nothing in flight, nothing left
             }
@@ -507,7 +552,7 @@ __global__ __launch_bounds__(64, RT_WF2_TRACE_WAVES) void wf2_trace_kernel(const
                 }
                 if (worth) {
                     if constexpr (LIST)
-                        top = wf2_leaf_list(S, W, top, s, ray, limit, cx, anc0, anc1);
+                        top = wf2_leaf_list(S, W, top, s, ray, limit, cx, anc0, anc1, keep_lo, keep_hi);
                     else
                         hit_shadow = wf2_leaf<SHADOW>(S, s, ray, limit, best, cx, anc0, anc1);
                 }
@@ -538,11 +583,60 @@ __global__ __launch_bounds__(64, RT_WF2_TRACE_WAVES) void wf2_trace_kernel(const
             // the containers loop over a finished list: once per wave and chunk, when its last walk is through -- lane by
             // lane as the walks end it ran with one or two lanes at a time and was a quarter of this kernel
             const bool through = busy && w.cur == RT_BVH4_DONE && p_n == 0u;
-            if (__builtin_amdgcn_ballot_w64(busy && !through) == 0ull && through) {
+            const bool all_through = __builtin_amdgcn_ballot_w64(busy && !through) == 0ull;
+            if (all_through && split == 1u && through) {
                 double n1, n2;
                 if (!containers_in_registers(S, W, top, ctx_f(sp, slot, CX_T), n1, n2)) containers_from_list(S, W, top, ctx_f(sp, slot, CX_T), n1, n2);
                 ctx_f(sp, slot, CX_N1) = n1;
                 ctx_f(sp, slot, CX_N2) = n2;
+                busy = false;
+            } else if (all_through && split > 1u && __builtin_amdgcn_ballot_w64(through) != 0ull) {
+                // a line's lists in the order of their ranges, the loop's state from lane to lane (every lane of the wave
+                // takes part in the exchanges; those without a ray hold nothing)
+                const unsigned sub = lane & (split - 1u);
+                const double hit_t = through ? ctx_f(sp, slot, CX_T) : 0.0;
+                ContainersState st;
+                containers_begin(st);
+                for (unsigned k = 0; k < split; ++k) {
+                    if (k != 0u) {
+                        ContainersState in;
+                        in.c0 = (uint32_t)__shfl_up((int)st.c0, 1, 64), in.c1 = (uint32_t)__shfl_up((int)st.c1, 1, 64);
+                        in.c2 = (uint32_t)__shfl_up((int)st.c2, 1, 64), in.c3 = (uint32_t)__shfl_up((int)st.c3, 1, 64);
+                        in.nc = __shfl_up(st.nc, 1, 64), in.phase = __shfl_up(st.phase, 1, 64);
+                        in.n1 = __shfl_up(st.n1, 1, 64), in.n2 = __shfl_up(st.n2, 1, 64);
+                        if (sub == k) st = in;
+                    }
+                    if (through && sub == k) containers_run(S, W, top, hit_t, st);
+                }
+                // a line with more than four objects open at once: its first lane gathers the lists (ascending ranges: every
+                // entry is appended) and answers from the whole list
+                const int last_phase = __shfl(st.phase, (int)(lane | (split - 1u)), 64);
+                const bool gather = through && last_phase == 2;
+                if (__builtin_amdgcn_ballot_w64(gather) != 0ull) {
+                    const int first = (int)(lane & ~(split - 1u));
+                    int all = top;
+                    for (unsigned k = 1; k < split; ++k) {
+                        const int n_k = __shfl(top, first + (int)k, 64);
+                        for (int j = 0; __builtin_amdgcn_ballot_w64(gather && j < n_k) != 0ull; ++j) {
+                            const bool mine = through && sub == k && j < top;
+                            const double t_j = mine ? W.LT(j) : 0.0;
+                            const uint32_t id_j = mine ? W.LID(j) : 0u;
+                            const double t_in = __shfl(t_j, first + (int)k, 64);
+                            const uint32_t id_in = (uint32_t)__shfl((int)id_j, first + (int)k, 64);
+                            if (gather && sub == 0u && j < n_k) all = list_insert(W, 0, all, t_in, id_in, cx.status);
+                        }
+                    }
+                    if (gather && sub == 0u) {
+                        double n1, n2;
+                        containers_from_list(S, W, all, hit_t, n1, n2);
+                        ctx_f(sp, slot, CX_N1) = n1;
+                        ctx_f(sp, slot, CX_N2) = n2;
+                    }
+                }
+                if (through && sub == split - 1u && st.phase != 2) {
+                    ctx_f(sp, slot, CX_N1) = st.n1;
+                    ctx_f(sp, slot, CX_N2) = st.n2;
+                }
                 busy = false;
             }
         } else if (busy && w.cur == RT_BVH4_DONE && p_n == 0u) {
