@@ -145,3 +145,31 @@ def test_host_frame_in_bands_equals_one_launch():
         assert np.array_equal(scene.render(cam).pixels, one), name
         assert np.array_equal(scene.render_rgb8(cam), orc.quantize(one)), name
         scene.close()
+
+
+def test_narrow_shares_of_a_4k_frame_equal_the_frame():
+    """A rank's share of the default bench frame (10 000 primitives, 4096x2160) dealt to 8 and to 32 ranks: launches with
+    fewer rays than the device has lanes, where a wave takes one uneven chunk and a containers line is shared out among
+    2-8 neighbouring lanes (rt_wf2.h).  Every share must hold exactly the rows of the frame rendered in one piece."""
+    import torch
+    from raytracer_amd import tiling
+    W, H = 4096, 2160
+    world, cam = rt.synthetic(W, H, 10000)
+    scene = rt.DeviceScene(world.flatten())
+    cd = cam.desc()
+    full = torch.zeros((H, W, 3), dtype=torch.float64, device="cuda")
+    scene.render_rows(cd, 5, 0, 1, H, H, full.data_ptr())
+    torch.cuda.synchronize()
+    scene.status()
+    band = tiling.DEFAULT_BAND_ROWS
+    for n_parts, parts in ((8, (0, 5)), (32, (0, 13, 31))):
+        for part in parts:
+            rows = tiling.n_local_rows(H, part, n_parts, band)
+            buf = torch.zeros((tiling.padded_local_rows(H, n_parts, band), W, 3), dtype=torch.float64, device="cuda")
+            scene.render_rows(cd, 5, part, n_parts, band, rows, buf.data_ptr())
+            torch.cuda.synchronize()
+            scene.status()
+            image_rows = tiling.image_rows(H, part, n_parts, band)
+            assert len(image_rows) == rows
+            assert torch.equal(buf[:rows], full.index_select(0, torch.as_tensor(image_rows, device="cuda"))), (n_parts, part)
+    scene.close()
