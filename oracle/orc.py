@@ -47,6 +47,7 @@ _sig("orc_matrix_mul", None, _dp, _dp, _dp)
 _sig("orc_schlick", C.c_double, _dp, _dp, C.c_double, C.c_double)
 _sig("orc_intersection_allowed", C.c_int, C.c_int, C.c_int, C.c_int, C.c_int)
 _sig("orc_perturb_noise", C.c_double, C.c_double, C.c_double, C.c_double)
+_sig("orc_noise_permutation", None, C.POINTER(C.c_uint8))
 _sig("orc_quantize", None, _dp, C.c_size_t, C.POINTER(C.c_uint8))
 _sig("orc_to_ppm", C.c_size_t, _dp, C.c_int, C.c_int, C.c_char_p, C.c_size_t)
 _sig("orc_exercise_shading", None, _dp)

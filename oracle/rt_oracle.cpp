@@ -16,10 +16,12 @@
 // Pinning: byte-exact against images/ppm/shading.ppm and pixel
 // parity against the nine 2048x1080 golden renders (tests/golden/*.png), plus the
 // reference's unit-test known answers (tests/test_oracle_kat.py).
-// NOT pinned: the Perturb pattern.  The reference calls noise::SuperSimplex
-// (crate `noise` 0.7.0, Cargo.lock:275-283), which is absent from
-// /root/reference; `perturb_noise` below is an in-repo Perlin "improved noise"
-// standing in for it => Perturb is "parity unpinned" at source level.
+// The Perturb pattern calls noise::SuperSimplex (crate `noise` 0.7.0,
+// Cargo.lock:275-283), a dependency that is absent from /root/reference:
+// `perturb_noise` below restates its published algorithm (and rand 0.7.3 /
+// rand_xorshift 0.2.0's for the seed-0 permutation table) and is pinned by the
+// reference's own render of exercises/pattern.rs: the Perturb sphere's pixels
+// of images/png/pattern.png come out identical.
 //
 // Arithmetic: IEEE binary64, one rounding per written operation.  Build with
 // -O2 -ffp-contract=off -fno-fast-math (oracle/Makefile).
@@ -192,46 +194,98 @@ struct Pattern {  // pattern.rs:13-18
     std::unique_ptr<Pattern> a, b;
 };
 
-// Stand-in for noise::SuperSimplex (see header): Ken Perlin's 2002 "improved
-// noise" with his reference permutation.  The HIP kernel carries the same
-// table and the same operation order.
-const uint8_t PERLIN_PERM[256] = {
-    151, 160, 137, 91,  90,  15,  131, 13,  201, 95,  96,  53,  194, 233, 7,   225, 140, 36,  103, 30,  69,  142,
-    8,   99,  37,  240, 21,  10,  23,  190, 6,   148, 247, 120, 234, 75,  0,   26,  197, 62,  94,  252, 219, 203,
-    117, 35,  11,  32,  57,  177, 33,  88,  237, 149, 56,  87,  174, 20,  125, 136, 171, 168, 68,  175, 74,  165,
-    71,  134, 139, 48,  27,  166, 77,  146, 158, 231, 83,  111, 229, 122, 60,  211, 133, 230, 220, 105, 92,  41,
-    55,  46,  245, 40,  244, 102, 143, 54,  65,  25,  63,  161, 1,   216, 80,  73,  209, 76,  132, 187, 208, 89,
-    18,  169, 200, 196, 135, 130, 116, 188, 159, 86,  164, 100, 109, 198, 173, 186, 3,   64,  52,  217, 226, 250,
-    124, 123, 5,   202, 38,  147, 118, 126, 255, 82,  85,  212, 207, 206, 59,  227, 47,  16,  58,  17,  182, 189,
-    28,  42,  223, 183, 170, 213, 119, 248, 152, 2,   44,  154, 163, 70,  221, 153, 101, 155, 167, 43,  172, 9,
-    129, 22,  39,  253, 19,  98,  108, 110, 79,  113, 224, 232, 178, 185, 112, 104, 218, 246, 97,  228, 251, 34,
-    242, 193, 238, 210, 144, 12,  191, 179, 162, 241, 81,  51,  145, 235, 249, 14,  239, 107, 49,  192, 214, 31,
-    181, 199, 106, 157, 184, 84,  204, 176, 115, 121, 50,  45,  127, 4,   150, 254, 138, 236, 205, 93,  222, 114,
-    67,  29,  24,  72,  243, 141, 128, 195, 78,  66,  215, 61,  156, 180};
-inline int perm(int i) { return PERLIN_PERM[i & 255]; }
-inline double fade(double t) { return t * t * t * (t * (t * 6.0 - 15.0) + 10.0); }
-inline double lerp(double t, double a, double b) { return a + t * (b - a); }
-inline double grad(int hash, double x, double y, double z) {
-    const int h = hash & 15;
-    const double u = h < 8 ? x : y;
-    const double v = h < 4 ? y : (h == 12 || h == 14 ? x : z);
-    return ((h & 1) == 0 ? u : -u) + ((h & 2) == 0 ? v : -v);
+// ---- noise::SuperSimplex (crate `noise` 0.7.0, Cargo.lock:275-283; seed 0 = SuperSimplex::new()) ---------------------
+// The crate is not part of /root/reference; this restates its published algorithm:
+//   * PermutationTable::new(0): the seed bytes [1, 0, 0, ...] into rand_xorshift 0.2.0's XorShiftRng (x = 1, y = z = w = 0),
+//     then (0..=255) shuffled by rand 0.7.3's SliceRandom::shuffle -- `for i in (1..len).rev() { swap(i, gen_range(0, i + 1)) }`
+//     -- with UniformInt::<u32>::sample_single (widening multiply, zone = (range << leading_zeros) - 1);
+//   * get([x, y, z]): the point into simplex space, p' = -(p + (x + y + z) * -2/3); two cubic lattices, the second moved
+//     by 512.5; of the eight corners of the cell around p' on each lattice those with attn = 0.75 - |d|^2 > 0 contribute
+//     attn^4 * dot(gradient(hash(corner)), d) (the crate looks the at most four such corners up in a table: the same set);
+//     hash = perm[perm[perm[x & 255] ^ (y & 255)] ^ (z & 255)]; gradient = index % 32 into "12 edges repeated twice then 8
+//     corners"; the sum times 1 / 0.0867664001655369.
+// PINNED by the reference's own render: every pixel of images/png/pattern.png whose primary hit is the Perturb sphere
+// (333 k pixels) comes out identical (tests/test_oracle_golden.py).
+struct XorShift {  // rand_xorshift 0.2.0
+    uint32_t x, y, z, w;
+    uint32_t next() {
+        const uint32_t t = x ^ (x << 11);
+        x = y, y = z, z = w;
+        w = w ^ (w >> 19) ^ (t ^ (t >> 8));
+        return w;
+    }
+};
+struct SsPermutation {
+    uint8_t v[256];
+    SsPermutation() {
+        XorShift r{1u, 0u, 0u, 0u};
+        for (int i = 0; i < 256; ++i) v[i] = static_cast<uint8_t>(i);
+        for (uint32_t i = 255; i >= 1; --i) {
+            const uint32_t range = i + 1u;  // gen_range(0, i + 1)
+            const uint32_t zone = (range << __builtin_clz(range)) - 1u;
+            uint32_t pick;
+            for (;;) {
+                const uint64_t m = static_cast<uint64_t>(r.next()) * range;
+                if (static_cast<uint32_t>(m) <= zone) {
+                    pick = static_cast<uint32_t>(m >> 32);
+                    break;
+                }
+            }
+            std::swap(v[i], v[pick]);
+        }
+    }
+};
+const SsPermutation SS_PERM;
+// Rust `f64 as isize`: saturating, NaN -> 0.
+inline int64_t f64_as_i64(double v) {
+    if (std::isnan(v)) return 0;
+    if (v >= 9223372036854775807.0) return INT64_MAX;
+    if (v <= -9223372036854775808.0) return INT64_MIN;
+    return static_cast<int64_t>(v);
+}
+inline void ss_gradient(unsigned index, double* g) {  // gradient::get3
+    const double diag = 0.70710678118654752440, diag2 = 0.5773502691896258;
+    const unsigned k = index % 32u;
+    if (k < 24u) {
+        const unsigned e = k % 12u, pair = e >> 2, s = e & 3u;  // pair 0: (x, y), 1: (x, z), 2: (y, z); signs: bit 0 first, bit 1 second
+        const double a = (s & 1u) ? -diag : diag, b = (s & 2u) ? -diag : diag;
+        g[0] = pair == 2u ? 0.0 : a;
+        g[1] = pair == 0u ? b : (pair == 2u ? a : 0.0);
+        g[2] = pair == 0u ? 0.0 : b;
+    } else {
+        const unsigned c = k - 24u;
+        g[0] = (c & 1u) ? -diag2 : diag2, g[1] = (c & 2u) ? -diag2 : diag2, g[2] = (c & 4u) ? -diag2 : diag2;
+    }
 }
 double perturb_noise(double x, double y, double z) {
-    const double fx = std::floor(x), fy = std::floor(y), fz = std::floor(z);
-    // wrap the lattice cell to 0..255 without overflowing an int for huge inputs
-    const int X = static_cast<int>(std::fmod(fx, 256.0) + 256.0) & 255;
-    const int Y = static_cast<int>(std::fmod(fy, 256.0) + 256.0) & 255;
-    const int Z = static_cast<int>(std::fmod(fz, 256.0) + 256.0) & 255;
-    x -= fx, y -= fy, z -= fz;
-    const double u = fade(x), v = fade(y), w = fade(z);
-    const int A = perm(X) + Y, AA = perm(A) + Z, AB = perm(A + 1) + Z;
-    const int B = perm(X + 1) + Y, BA = perm(B) + Z, BB = perm(B + 1) + Z;
-    return lerp(w,
-                lerp(v, lerp(u, grad(perm(AA), x, y, z), grad(perm(BA), x - 1.0, y, z)),
-                     lerp(u, grad(perm(AB), x, y - 1.0, z), grad(perm(BB), x - 1.0, y - 1.0, z))),
-                lerp(v, lerp(u, grad(perm(AA + 1), x, y, z - 1.0), grad(perm(BA + 1), x - 1.0, y, z - 1.0)),
-                     lerp(u, grad(perm(AB + 1), x, y - 1.0, z - 1.0), grad(perm(BB + 1), x - 1.0, y - 1.0, z - 1.0))));
+    const double off = ((x + y) + z) * (-2.0 / 3.0);
+    const double sp[3] = {-(x + off), -(y + off), -(z + off)};
+    double value = 0.0;
+    for (int lattice = 0; lattice < 2; ++lattice) {
+        double rel[3];
+        uint64_t bi[3];
+        for (int a = 0; a < 3; ++a) {
+            const double p = lattice == 0 ? sp[a] : sp[a] + 512.5;
+            const double base = std::floor(p);
+            bi[a] = static_cast<uint64_t>(f64_as_i64(base));
+            rel[a] = p - base;
+        }
+        for (unsigned c = 0; c < 8u; ++c) {
+            const unsigned ox = c & 1u, oy = (c >> 1) & 1u, oz = (c >> 2) & 1u;
+            const double dx = rel[0] - static_cast<double>(ox), dy = rel[1] - static_cast<double>(oy), dz = rel[2] - static_cast<double>(oz);
+            const double attn = 0.75 - ((dx * dx + dy * dy) + dz * dz);
+            if (attn > 0.0) {
+                const unsigned hx = SS_PERM.v[static_cast<unsigned>((bi[0] + ox) & 0xffu)];
+                const unsigned hy = SS_PERM.v[hx ^ static_cast<unsigned>((bi[1] + oy) & 0xffu)];
+                const unsigned hz = SS_PERM.v[hy ^ static_cast<unsigned>((bi[2] + oz) & 0xffu)];
+                double g[3];
+                ss_gradient(hz, g);
+                const double a2 = attn * attn;
+                value += (a2 * a2) * ((g[0] * dx + g[1] * dy) + g[2] * dz);
+            }
+        }
+    }
+    return value * (1.0 / 0.0867664001655369);
 }
 
 // Rust `f64 as i32`: saturating, NaN -> 0.
@@ -1267,6 +1321,7 @@ int orc_intersection_allowed(int op, int l_hit, int in_l, int in_r) {
     return intersection_allowed(op, l_hit != 0, in_l != 0, in_r != 0) ? 1 : 0;
 }
 double orc_perturb_noise(double x, double y, double z) { return perturb_noise(x, y, z); }
+void orc_noise_permutation(uint8_t* out) { std::memcpy(out, SS_PERM.v, 256); }
 
 void orc_quantize(const double* rgb, size_t n_values, uint8_t* out) {
     for (size_t i = 0; i < n_values; ++i) out[i] = scale_to_ppm_data(rgb[i]);
