@@ -228,46 +228,79 @@ RT_DEV V3 cube_normal(V3 p) {
     return v3(0.0, 0.0, p.z);
 }
 
-// ---- Perturb noise ------------------------------------------------------------
-// The reference calls noise::SuperSimplex (crate `noise` 0.7.0), which is not part
-// of the reference tree; this is Ken Perlin's 2002 improved noise with his
-// reference permutation, the documented stand-in (DESIGN.md "Perturb").
-__device__ const uint8_t PERLIN_PERM[256] = {
-    151, 160, 137, 91,  90,  15,  131, 13,  201, 95,  96,  53,  194, 233, 7,   225, 140, 36,  103, 30,  69,  142,
-    8,   99,  37,  240, 21,  10,  23,  190, 6,   148, 247, 120, 234, 75,  0,   26,  197, 62,  94,  252, 219, 203,
-    117, 35,  11,  32,  57,  177, 33,  88,  237, 149, 56,  87,  174, 20,  125, 136, 171, 168, 68,  175, 74,  165,
-    71,  134, 139, 48,  27,  166, 77,  146, 158, 231, 83,  111, 229, 122, 60,  211, 133, 230, 220, 105, 92,  41,
-    55,  46,  245, 40,  244, 102, 143, 54,  65,  25,  63,  161, 1,   216, 80,  73,  209, 76,  132, 187, 208, 89,
-    18,  169, 200, 196, 135, 130, 116, 188, 159, 86,  164, 100, 109, 198, 173, 186, 3,   64,  52,  217, 226, 250,
-    124, 123, 5,   202, 38,  147, 118, 126, 255, 82,  85,  212, 207, 206, 59,  227, 47,  16,  58,  17,  182, 189,
-    28,  42,  223, 183, 170, 213, 119, 248, 152, 2,   44,  154, 163, 70,  221, 153, 101, 155, 167, 43,  172, 9,
-    129, 22,  39,  253, 19,  98,  108, 110, 79,  113, 224, 232, 178, 185, 112, 104, 218, 246, 97,  228, 251, 34,
-    242, 193, 238, 210, 144, 12,  191, 179, 162, 241, 81,  51,  145, 235, 249, 14,  239, 107, 49,  192, 214, 31,
-    181, 199, 106, 157, 184, 84,  204, 176, 115, 121, 50,  45,  127, 4,   150, 254, 138, 236, 205, 93,  222, 114,
-    67,  29,  24,  72,  243, 141, 128, 195, 78,  66,  215, 61,  156, 180};
-RT_DEV int perm(int i) { return PERLIN_PERM[i & 255]; }
-RT_DEV double fade(double t) { return t * t * t * (t * (t * 6.0 - 15.0) + 10.0); }
-RT_DEV double lerp(double t, double a, double b) { return a + t * (b - a); }
-RT_DEV double grad(int hash, double x, double y, double z) {
-    const int h = hash & 15;
-    const double u = h < 8 ? x : y;
-    const double v = h < 4 ? y : (h == 12 || h == 14 ? x : z);
-    return ((h & 1) == 0 ? u : -u) + ((h & 2) == 0 ? v : -v);
+// ---- Perturb noise: noise::SuperSimplex (crate `noise` 0.7.0, seed 0 = SuperSimplex::new(), pattern.rs:107-124) ------
+// The crate is a dependency outside the reference tree; oracle/rt_oracle.cpp restates its published algorithm and derives
+// this permutation table (PermutationTable::new(0): rand_xorshift 0.2.0 + rand 0.7.3's shuffle), and the reference's own
+// render pins both: every Perturb pixel of images/png/pattern.png comes out identical.  tests/test_host_logic.py compares
+// the table below with the oracle's derivation; the arithmetic is the oracle's, operation for operation.
+//   point into simplex space: p' = -(p + (x + y + z) * -2/3); two cubic lattices, the second moved by 512.5; of the eight
+//   corners of the cell around p' on each lattice those with attn = 0.75 - |d|^2 > 0 contribute attn^4 * dot(gradient, d);
+//   hash = perm[perm[perm[x & 255] ^ (y & 255)] ^ (z & 255)]; gradients: 12 cube edges repeated twice, then 8 corners;
+//   the sum times 1 / 0.0867664001655369.
+__device__ const uint8_t SS_PERM[256] = {
+    181, 206, 3, 127, 58, 121, 169, 47, 62, 123, 5, 142, 99, 140, 178, 171, 114, 60, 194, 65, 135, 190,
+    85, 125, 208, 234, 39, 9, 182, 82, 92, 132, 212, 95, 160, 31, 84, 75, 90, 52, 108, 6, 7, 204,
+    163, 19, 172, 122, 168, 63, 205, 111, 224, 166, 21, 59, 203, 88, 116, 104, 68, 13, 26, 170, 102, 220,
+    159, 72, 77, 120, 196, 67, 185, 66, 27, 79, 144, 118, 219, 55, 139, 91, 183, 146, 113, 202, 207, 241,
+    89, 29, 83, 130, 71, 10, 46, 87, 152, 211, 106, 145, 201, 51, 109, 232, 81, 134, 186, 78, 74, 137,
+    124, 115, 184, 32, 165, 188, 57, 16, 175, 192, 128, 174, 180, 119, 117, 228, 221, 40, 110, 149, 96, 80,
+    210, 94, 200, 86, 34, 97, 100, 156, 73, 155, 197, 45, 42, 44, 153, 191, 214, 173, 126, 187, 24, 223,
+    30, 38, 193, 199, 101, 225, 8, 231, 176, 25, 148, 37, 33, 136, 12, 76, 198, 98, 105, 93, 69, 53,
+    23, 150, 56, 107, 151, 162, 141, 36, 189, 143, 50, 48, 195, 112, 131, 138, 147, 209, 226, 215, 227, 61,
+    222, 218, 177, 103, 167, 129, 64, 35, 239, 154, 161, 179, 213, 41, 22, 217, 216, 229, 54, 70, 20, 233,
+    11, 164, 158, 18, 133, 157, 28, 43, 243, 230, 14, 49, 240, 235, 236, 4, 237, 238, 244, 17, 1, 242,
+    2, 15, 245, 246, 247, 248, 249, 250, 251, 252, 253, 254, 255, 0};
+// Rust `f64 as isize`: saturating, NaN -> 0
+RT_DEV long long f64_as_i64(double v) {
+    if (v != v) return 0;
+    if (v >= 9223372036854775807.0) return 9223372036854775807ll;
+    if (v <= -9223372036854775808.0) return (-9223372036854775807ll - 1);
+    return (long long)v;
 }
 __device__ __noinline__ double perturb_noise(double x, double y, double z) {
-    const double fx = floor(x), fy = floor(y), fz = floor(z);
-    const int X = (int)(fmod(fx, 256.0) + 256.0) & 255;
-    const int Y = (int)(fmod(fy, 256.0) + 256.0) & 255;
-    const int Z = (int)(fmod(fz, 256.0) + 256.0) & 255;
-    x -= fx, y -= fy, z -= fz;
-    const double u = fade(x), v = fade(y), w = fade(z);
-    const int A = perm(X) + Y, AA = perm(A) + Z, AB = perm(A + 1) + Z;
-    const int B = perm(X + 1) + Y, BA = perm(B) + Z, BB = perm(B + 1) + Z;
-    return lerp(w,
-                lerp(v, lerp(u, grad(perm(AA), x, y, z), grad(perm(BA), x - 1.0, y, z)),
-                     lerp(u, grad(perm(AB), x, y - 1.0, z), grad(perm(BB), x - 1.0, y - 1.0, z))),
-                lerp(v, lerp(u, grad(perm(AA + 1), x, y, z - 1.0), grad(perm(BA + 1), x - 1.0, y, z - 1.0)),
-                     lerp(u, grad(perm(AB + 1), x, y - 1.0, z - 1.0), grad(perm(BB + 1), x - 1.0, y - 1.0, z - 1.0))));
+    const double off = ((x + y) + z) * (-2.0 / 3.0);
+    const double sp[3] = {-(x + off), -(y + off), -(z + off)};
+    double value = 0.0;
+#pragma unroll
+    for (int lattice = 0; lattice < 2; ++lattice) {
+        double rel[3];
+        unsigned long long bi[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double p = lattice == 0 ? sp[a] : sp[a] + 512.5;
+            const double base = floor(p);
+            bi[a] = (unsigned long long)f64_as_i64(base);
+            rel[a] = p - base;
+        }
+#pragma unroll
+        for (unsigned c = 0; c < 8u; ++c) {
+            const unsigned ox = c & 1u, oy = (c >> 1) & 1u, oz = (c >> 2) & 1u;
+            const double dx = rel[0] - (double)ox, dy = rel[1] - (double)oy, dz = rel[2] - (double)oz;
+            const double attn = 0.75 - ((dx * dx + dy * dy) + dz * dz);
+            if (attn > 0.0) {
+                const unsigned hx = SS_PERM[(unsigned)((bi[0] + ox) & 0xffu)];
+                const unsigned hy = SS_PERM[hx ^ (unsigned)((bi[1] + oy) & 0xffu)];
+                const unsigned hz = SS_PERM[hy ^ (unsigned)((bi[2] + oz) & 0xffu)];
+                // gradient::get3(index % 32): "12 edges repeated twice then 8 corners"
+                const double diag = 0.70710678118654752440, diag2 = 0.5773502691896258;
+                const unsigned k = hz % 32u;
+                double gx, gy, gz;
+                if (k < 24u) {
+                    const unsigned e = k % 12u, pair = e >> 2, sg = e & 3u;  // pair 0: (x, y), 1: (x, z), 2: (y, z)
+                    const double a = (sg & 1u) ? -diag : diag, b = (sg & 2u) ? -diag : diag;
+                    gx = pair == 2u ? 0.0 : a;
+                    gy = pair == 0u ? b : (pair == 2u ? a : 0.0);
+                    gz = pair == 0u ? 0.0 : b;
+                } else {
+                    const unsigned cc = k - 24u;
+                    gx = (cc & 1u) ? -diag2 : diag2, gy = (cc & 2u) ? -diag2 : diag2, gz = (cc & 4u) ? -diag2 : diag2;
+                }
+                const double a2 = attn * attn;
+                value += (a2 * a2) * ((gx * dx + gy * dy) + gz * dz);
+            }
+        }
+    }
+    return value * (1.0 / 0.0867664001655369);
 }
 
 // Rust `f64 as i32`: saturating, NaN -> 0 (pattern.rs:159,183,193)

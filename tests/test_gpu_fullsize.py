@@ -3,7 +3,7 @@ artefact exists:
 
 * the nine render exercises at the goldens' own 2048x1080, quantised on the device, against
   tests/golden/<scene>.png (the reference's renders, images/png/*.png; canvas.rs:85-90 for the
-  8-bit rule) -- same thresholds and Perturb mask as tests/test_oracle_golden.py;
+  8-bit rule) -- same thresholds as tests/test_oracle_golden.py, the Perturb sphere of pattern.png on its own as well;
 * the exercises no other test renders above 512x270, row-sampled against the oracle at 2048x1080;
 * BASELINE.json config 5 at its stated size: 10 000 primitives at 7680x4320 (camera.rs:51-66 over the
   synthetic scene): one launch of all rows == 8 interleaved row-band shards reassembled, bit for bit;
@@ -33,8 +33,8 @@ def test_gpu_render_matches_golden_png(name):
     diff = np.abs(got.astype(int) - want.astype(int)).max(axis=2)
     considered = np.ones(diff.shape, dtype=bool)
     if name == "pattern":
-        # Perturb ("parity unpinned": noise::SuperSimplex is not in the reference tree): leave out the pixels
-        # whose camera ray hits the middle sphere (shape 3), found with the GPU probe, grown by one pixel
+        # Perturb (noise::SuperSimplex, restated: rt_device.h): the pixels whose camera ray hits the middle sphere
+        # (shape 3), found with the GPU probe, are held to the same bar on their own
         cd = cam.desc()
         inv = np.array(list(cd.inv)).reshape(4, 4)
         xs, ys = np.arange(cam.h_size), np.arange(cam.v_size)
@@ -48,10 +48,10 @@ def test_gpu_render_matches_golden_png(name):
         probe = world.probe(rays).reshape(len(ys), len(xs), 16)
         perturbed = (probe[..., 0] == 1.0) & (probe[..., 2] == 3.0)
         assert 0.10 < perturbed.mean() < 0.20  # 333 111 px = 15 %
-        grown = perturbed.copy()
-        grown[1:] |= perturbed[:-1]; grown[:-1] |= perturbed[1:]
-        grown[:, 1:] |= perturbed[:, :-1]; grown[:, :-1] |= perturbed[:, 1:]
-        considered = ~grown
+        on_sphere = int(perturbed.sum())
+        off = int(((diff > 0) & perturbed).sum())
+        print(f"pattern: GPU vs golden PNG: {off}/{on_sphere} Perturb pixels differ")
+        assert off <= 1e-3 * on_sphere
     n = int(considered.sum())
     differ = int(((diff > 0) & considered).sum())
     beyond_lsb = int(((diff > 1) & considered).sum())

@@ -305,3 +305,15 @@ def test_hierarchy_does_not_depend_on_the_builder_threads(monkeypatch):
     b = fb.desc.contents
     assert b.n_bvh_nodes == a.n_bvh_nodes and b.world_bvh_root == a.world_bvh_root
     assert C.string_at(b.bvh_nodes, b.n_bvh_nodes * C.sizeof(b.bvh_nodes._type_)) == nodes_a
+
+
+def test_noise_permutation_table_in_the_kernels_is_the_derived_one():
+    """noise::SuperSimplex::new() = seed 0: the oracle derives PermutationTable::new(0) from rand_xorshift 0.2.0 and
+    rand 0.7.3's shuffle (and pattern.png pins the result); the kernels carry the table as a constant."""
+    import os, re
+    src = open(os.path.join(os.path.dirname(__file__), "..", "raytracer_amd", "csrc", "rt_device.h")).read()
+    body = re.search(r"SS_PERM\[256\] = \{([^}]*)\}", src).group(1)
+    table = [int(v) for v in body.replace("\n", " ").split(",")]
+    derived = (C.c_uint8 * 256)()
+    orc.lib.orc_noise_permutation(derived)
+    assert table == list(derived) and sorted(table) == list(range(256))

@@ -5,8 +5,9 @@
 * tests/golden/<scene>.png are the reference's 2048x1080 renders (images/png/*.png, lossless
   stand-ins for the PPMs missing from the mount).  Bar: 8-bit values identical except on
   <= 0.1 % of pixels (north_star); in practice a handful of seam pixels.
-* pattern.png: pixels whose primary hit is the Perturb sphere are excluded -- the reference
-  calls the `noise` crate, which is not in the tree ("parity unpinned" for Perturb).
+* pattern.png: the Perturb sphere calls the `noise` crate (0.7.0), which is not in the tree; the oracle restates
+  SuperSimplex and its seed-0 permutation table from the published algorithm, and THIS image pins the restatement:
+  the pixels whose primary hit is the Perturb sphere (15 % of the frame) are held to the same bar on their own.
 Heavy scenes are compared on a row subsample so the CPU suite stays within minutes.
 """
 import os
@@ -65,11 +66,11 @@ def test_oracle_matches_golden_png(name):
         probe = ow.probe(rays).reshape(len(ys), len(xs), 16)
         perturbed = (probe[..., 0] == 1.0) & (probe[..., 2] == 3.0)
         assert 0.10 < perturbed.mean() < 0.20  # SURVEY: 333 111 px = 15 %
-        # one-pixel dilation so that float noise in this mask's rays cannot leak an edge pixel
-        grown = perturbed.copy()
-        grown[1:] |= perturbed[:-1]; grown[:-1] |= perturbed[1:]
-        grown[:, 1:] |= perturbed[:, :-1]; grown[:, :-1] |= perturbed[:, 1:]
-        considered = ~grown
+        # the Perturb pixels on their own: noise::SuperSimplex as restated in oracle/rt_oracle.cpp is what the reference ran
+        on_sphere = int(perturbed.sum())
+        off = int(((diff > 0) & perturbed).sum())
+        print(f"pattern: {off}/{on_sphere} Perturb pixels differ from the golden render")
+        assert off <= 1e-3 * on_sphere
     n = int(considered.sum())
     differ = int(((diff > 0) & considered).sum())
     beyond_lsb = int(((diff > 1) & considered).sum())
