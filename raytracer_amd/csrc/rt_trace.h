@@ -525,7 +525,16 @@ RT_DEV int list_eval_core(const SceneDev& S, SW& W, int begin, int end, int leve
         } else if (cur < lend) {
             s = cur;
             cur = (int)S.shapes[s].skip;
+            // The right operand of an intersection or a difference whose LEFT operand has put nothing on the node's list: no
+            // left entry means in_l never turns true, and without it (l_hit && ..) || (!l_hit && in_l) passes no entry of
+            // either operand (compound.rs:142-181) -- the right operand need not be evaluated.  (Entries beyond `bound` are
+            // not on the list, and need not be: toggles there do not reach the entries before them.)
+            if (level > floor && top == base && s > W.fnode[level] + 1) {  // (level > floor: inside a compound this walk entered)
+                const RtShape* __restrict__ gs = S.shapes + W.fnode[level];
+                if (RT_KIND(gs->kind_flags) == RT_CSG && ((gs->kind_flags >> RT_FLAG_CSG_OP_SHIFT) & 3u) != 0u) s = -2;
+            }
         }
+        if (s == -2) continue;  // (skipped: on to whatever comes after it on this level -- nothing, for a CSG node)
         if (s < 0) {  // level exhausted
             if (level == floor) {
                 if (FLAT == RT_CLASS_NESTED_LEAVES && WORLD && resume >= -1) {  // back from a nested CSG node to the world walk
