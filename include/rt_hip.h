@@ -243,6 +243,8 @@ typedef struct RtStats {
     uint64_t container_passes;/* n1/n2 passes (second traversal)                */
     uint64_t list_entries;    /* hits materialised into per-lane lists          */
     uint64_t schlicks;
+    uint64_t accel_f32_tests; /* acceleration-only tests done in f32: child boxes of the 4-wide hierarchy (4 per node
+                                 visited) and the pre-tests of its leaves; NOT FP64 work (bvh_box_tests are f64)  */
     uint64_t status_flags;    /* OR of (1<<-err) run-time conditions            */
     double kernel_ms;         /* device time of the launch (hipEvent)           */
 } RtStats;
@@ -319,8 +321,10 @@ int rt_hip_render_rows(const RtScene* scene, const RtCameraDesc* cam, uint32_t d
  * the kernels work in a fixed 128 MiB array in device memory that belongs to the library (one copy per GPU
  * the library runs on, held until the process ends), rendering the rows in batches that fit it; every other
  * scene is rendered by the one-launch kernel (mode 0), which needs no workspace.
- * Limit: one batch is at least 8 rows, so hsize can be at most about 30 000 pixels; wider frames are refused
- * with RT_ERR_NOALLOC_SIZE.  Every call on one GPU shares that GPU's array (each call clears the counters it
+ * Limit: one batch is at least 8 rows, so hsize can be at most about 30 000 pixels (fewer with many lights: a hit holds one
+ * byte per light); wider frames are refused with RT_ERR_NOALLOC_SIZE -- a clear refusal rather than a silent change of
+ * kernels: rt_hip_scene_set_wavefront(scene, 0, 0, 0) before the call renders the same frame bit for bit with the
+ * one-launch kernel, which needs no workspace and has no such limit.  Every call on one GPU shares that GPU's array (each call clears the counters it
  * needs at zero): calls that overlap in time on one GPU -- other streams, other threads, other scenes --
  * race; order them.  rt_hip_scene_set_wavefront's capacities do not apply. */
 int rt_hip_render_rows_noalloc(const RtScene* scene, const RtCameraDesc* cam, uint32_t depth, uint32_t part,

@@ -122,7 +122,7 @@ class RtStats(C.Structure):
                 ("group_gates", C.c_uint64), ("bvh_box_tests", C.c_uint64), ("hits_shaded", C.c_uint64),
                 ("normal_levels", C.c_uint64), ("lightings", C.c_uint64), ("pow_calls", C.c_uint64),
                 ("pattern_nodes", C.c_uint64), ("container_passes", C.c_uint64), ("list_entries", C.c_uint64),
-                ("schlicks", C.c_uint64), ("status_flags", C.c_uint64), ("kernel_ms", C.c_double)]
+                ("schlicks", C.c_uint64), ("accel_f32_tests", C.c_uint64), ("status_flags", C.c_uint64), ("kernel_ms", C.c_double)]
 
     def as_dict(self):
         d = {}

@@ -109,7 +109,7 @@ RT_DEV void walk_step(const Wf2Accel& A, const RayF32& f, float t_near, float t_
     const uint4* __restrict__ q = reinterpret_cast<const uint4*>(A.nodes + w.cur);
     const uint4 w0 = q[0], w1 = q[1], w2 = q[2];  // org + exponents | children | qlo[3], qhi[0]
     const uint2 w3 = *reinterpret_cast<const uint2*>(q + 3);  // qhi[1], qhi[2]
-    count(cx, ST_BVH_BOX, 4u);
+    count(cx, ST_ACCEL_F32, 4u);
     const uint32_t kid[4] = {w1.x, w1.y, w1.z, w1.w};
     const uint32_t qlo[3] = {w2.x, w2.y, w2.z}, qhi[3] = {w2.w, w3.x, w3.y};
     // plane(axis, child) = org + q * step, so t = q * (step * inv) + (org * inv + c): the slack in c (ray_f32) also covers
@@ -487,7 +487,7 @@ RT_DEV bool trace4(const SceneDev& S, const Ray& ray, bool shadow, double limit,
             } else {
                 const float reach = fmaxf(fmaxf(fabsf((float)ray.o.x), fabsf((float)ray.o.y)), fabsf((float)ray.o.z)) * 1.000001f + A.extent_max;
                 worth = leaf_may_hit(A.pre + s, ray, reach, anc0, anc1);
-                count(cx, ST_BVH_BOX);
+                count(cx, ST_ACCEL_F32);
             }
         }
         if (worth) {

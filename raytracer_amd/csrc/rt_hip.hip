@@ -636,6 +636,16 @@ int rt_hip_scene_create(const RtSceneDesc* desc, RtScene** out) {
             if (!off && RT_KIND(mine[i].kind_flags) <= RT_SMOOTH_TRIANGLE && std::memcmp(mine[i].inv, kIdentity, sizeof kIdentity) == 0)
                 mine[i].kind_flags |= RT_FLAG_IDENTITY;
         }
+        // RT_FLAG_CSG_RIGHT_LHIT: from the l_hit table as handed in (whoever flattened the scene), so that the skip of the
+        // right operand in list_eval_core holds for tables of any origin
+        for (uint32_t i = 0; i < desc->n_shapes; ++i) {
+            mine[i].kind_flags &= ~RT_FLAG_CSG_RIGHT_LHIT;
+            if (RT_KIND(mine[i].kind_flags) != RT_CSG) continue;
+            const RtCsg& c = desc->csgs[mine[i].param];
+            const uint32_t right = mine[i + 1].skip;  // (validate: left = i + 1, right = left.skip, right.skip == skip)
+            for (uint32_t p = right; p < mine[i].skip; ++p)
+                if (desc->lhit[c.lhit_offset + (p - i - 1u)] != 0) mine[i].kind_flags |= RT_FLAG_CSG_RIGHT_LHIT;
+        }
     }
     const size_t o_conics = arena.add(desc->conics, sizeof(RtConic) * desc->n_conics);
     const size_t o_tris = arena.add(desc->triangles, sizeof(RtTriangle) * desc->n_triangles);

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
@@ -60,8 +61,10 @@ public:
     // One caller at a time (the copier's mutex).  begin(): the threads start waiting for chunks; arrived(k): chunks
     // [0, k) are in the staging buffer; finish(): blocks until every announced byte is copied (call arrived(n_chunks)
     // or abandon() first).
-    void begin(void* dst, const void* src, size_t bytes, size_t chunk) {
-        dst_ = static_cast<char*>(dst), src_ = static_cast<const char*>(src), bytes_ = bytes, chunk_ = chunk;
+    // `ring` chunks of staging: chunk c lies at src + (c % ring) * chunk
+    void begin(void* dst, const void* src, size_t bytes, size_t chunk, size_t ring) {
+        dst_ = static_cast<char*>(dst), src_ = static_cast<const char*>(src), bytes_ = bytes, chunk_ = chunk, ring_ = ring;
+        for (Progress& p : progress_) p.chunks.store(0, std::memory_order_relaxed);
         ready_.store(0, std::memory_order_relaxed);
         abandoned_.store(false, std::memory_order_relaxed);
         if (size() == 0) return;
@@ -78,6 +81,13 @@ public:
         }
         ready_.store(k, std::memory_order_release);
     }
+    // blocks until every thread has moved chunk c on (its slot of the staging ring may be written again)
+    void wait_consumed(size_t c) {
+        for (unsigned t = 0; t < size(); ++t) {
+            unsigned spins = 0;
+            while (progress_[t].chunks.load(std::memory_order_acquire) <= c && !abandoned_.load(std::memory_order_acquire)) nap(spins);
+        }
+    }
     void abandon() { abandoned_.store(true, std::memory_order_release); }
     void finish() {
         if (size() == 0) return;
@@ -86,10 +96,16 @@ public:
     }
 
 private:
+    // A short spin (a chunk's DMA takes ~0.3 ms: most waits are longer), then sleeps: eight threads spinning through every
+    // DMA of every large copy burn the cores the caller's other threads could use.
+    static void nap(unsigned& spins) {
+        if (++spins <= 256u) return;
+        std::this_thread::sleep_for(std::chrono::microseconds(spins < 4096u ? 20 : 200));
+    }
     void copy_slice(size_t c, unsigned t, unsigned n) {
         const size_t off = c * chunk_, len = bytes_ - off < chunk_ ? bytes_ - off : chunk_;
         const size_t a = len * t / n / 64 * 64, b = t + 1 == n ? len : len * (t + 1) / n / 64 * 64;
-        std::memcpy(dst_ + off + a, src_ + off + a, b - a);
+        std::memcpy(dst_ + off + a, src_ + (c % ring_) * chunk_ + a, b - a);
     }
     void run(unsigned t) {
         unsigned long seen = 0;
@@ -103,10 +119,10 @@ private:
             const size_t n_chunks = (bytes_ + chunk_ - 1) / chunk_;
             for (size_t c = 0; c < n_chunks; ++c) {
                 unsigned spins = 0;
-                while (ready_.load(std::memory_order_acquire) <= c && !abandoned_.load(std::memory_order_acquire))
-                    if (++spins > 64) std::this_thread::yield();
+                while (ready_.load(std::memory_order_acquire) <= c && !abandoned_.load(std::memory_order_acquire)) nap(spins);
                 if (ready_.load(std::memory_order_acquire) <= c) break;  // abandoned
                 copy_slice(c, t, size());
+                progress_[t].chunks.store(c + 1, std::memory_order_release);
             }
             {
                 std::lock_guard<std::mutex> lock(m_);
@@ -122,13 +138,18 @@ private:
     unsigned pending_ = 0;
     char* dst_ = nullptr;
     const char* src_ = nullptr;
-    size_t bytes_ = 0, chunk_ = 1;
+    size_t bytes_ = 0, chunk_ = 1, ring_ = 1;
+    struct alignas(64) Progress {
+        std::atomic<size_t> chunks{0};  // chunks this thread has moved on
+    };
+    Progress progress_[8];  // (at most eight threads: pool())
     std::atomic<size_t> ready_{0};
     std::atomic<bool> abandoned_{false};
 };
 
 // ---- staged device -> pageable host copies ------------------------------------------------------------------------
 constexpr size_t kChunk = 16u << 20;
+constexpr size_t kRing = 8;  // chunks of pinned staging per device: 128 MB whatever the frame (an 8K f64 frame is 800 MB)
 constexpr int kMaxDevices = 64;
 struct Copier {
     std::mutex m;
@@ -230,6 +251,14 @@ void rth::hostmem_shutdown() {
         if (c.stream) (void)hipStreamDestroy(c.stream);
         c.staging = nullptr, c.staging_bytes = 0, c.done.clear(), c.ready = nullptr, c.stream = nullptr;
     }
+    CopyPool* idle = nullptr;
+    {
+        std::lock_guard<std::mutex> use(g_pool_use_mutex);  // (no copy is using the threads)
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        idle = g_pool;
+        g_pool = nullptr;
+    }
+    delete idle;  // joins the copy threads (the next large copy starts new ones)
 }
 
 // Device -> the caller's (pageable) buffer.  A plain hipMemcpy into pageable memory runs at ~9 GB/s; here the DMA goes
@@ -249,10 +278,12 @@ int rth::copy_to_host(void* dst, const void* d_src, size_t bytes, hipStream_t pr
     std::lock_guard<std::mutex> lock(c.m);
     if (!c.stream) HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
     if (!c.ready) HIP_TRY(hipEventCreateWithFlags(&c.ready, hipEventDisableTiming));
-    if (c.staging_bytes < bytes) {
+    const size_t n_chunks = (bytes + kChunk - 1) / kChunk;
+    const size_t ring = n_chunks < kRing ? n_chunks : kRing;
+    if (c.staging_bytes < ring * kChunk) {
         if (c.staging) (void)hipHostFree(c.staging);
         c.staging = nullptr, c.staging_bytes = 0;
-        if (hipHostMalloc(&c.staging, bytes, hipHostMallocDefault) != hipSuccess) {  // no pinned memory to be had
+        if (hipHostMalloc(&c.staging, ring * kChunk, hipHostMallocDefault) != hipSuccess) {  // no pinned memory to be had
             (void)hipGetLastError();
             c.staging = nullptr;
             if (after) HIP_TRY(hipEventSynchronize(after));
@@ -260,10 +291,9 @@ int rth::copy_to_host(void* dst, const void* d_src, size_t bytes, hipStream_t pr
             HIP_TRY(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
             return RT_OK;
         }
-        c.staging_bytes = bytes;
+        c.staging_bytes = ring * kChunk;
     }
-    const size_t n_chunks = (bytes + kChunk - 1) / kChunk;
-    while (c.done.size() < n_chunks) {
+    while (c.done.size() < ring) {
         hipEvent_t e = nullptr;
         HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         c.done.push_back(e);
@@ -275,24 +305,31 @@ int rth::copy_to_host(void* dst, const void* d_src, size_t bytes, hipStream_t pr
         HIP_TRY(hipStreamWaitEvent(c.stream, c.ready, 0));
     }
     int rc = RT_OK;
-    for (size_t k = 0; k < n_chunks && rc == RT_OK; ++k) {
+    // chunk k goes through slot k % ring of the staging buffer: its DMA is issued once the host threads have moved chunk
+    // k - ring on, so `ring - 1` DMAs are queued while the threads work on one chunk
+    auto issue = [&](size_t k) {
         const size_t off = k * kChunk, len = bytes - off < kChunk ? bytes - off : kChunk;
-        if (hipMemcpyAsync(static_cast<char*>(c.staging) + off, static_cast<const char*>(d_src) + off, len, hipMemcpyDeviceToHost,
-                           c.stream) != hipSuccess ||
-            hipEventRecord(c.done[k], c.stream) != hipSuccess)
+        if (hipMemcpyAsync(static_cast<char*>(c.staging) + (k % ring) * kChunk, static_cast<const char*>(d_src) + off, len,
+                           hipMemcpyDeviceToHost, c.stream) != hipSuccess ||
+            hipEventRecord(c.done[k % ring], c.stream) != hipSuccess)
             rc = rth::hip_fail(hipGetLastError(), "staged device-to-host copy");
-    }
+    };
+    for (size_t k = 0; k < ring && rc == RT_OK; ++k) issue(k);
     if (rc == RT_OK) {
         CopyPool* workers = pool();
         std::lock_guard<std::mutex> pool_lock(g_pool_use_mutex);  // (copiers of different devices share the threads)
-        workers->begin(dst, c.staging, bytes, kChunk);
+        workers->begin(dst, c.staging, bytes, kChunk, ring);
         for (size_t k = 0; k < n_chunks; ++k) {
-            if (hipEventSynchronize(c.done[k]) != hipSuccess) {
-                rc = rth::hip_fail(hipGetLastError(), "hipEventSynchronize");
+            if (rc != RT_OK || hipEventSynchronize(c.done[k % ring]) != hipSuccess) {
+                if (rc == RT_OK) rc = rth::hip_fail(hipGetLastError(), "hipEventSynchronize");
                 workers->abandon();
                 break;
             }
             workers->arrived(k + 1);
+            if (k + ring < n_chunks) {
+                workers->wait_consumed(k);
+                issue(k + ring);
+            }
         }
         workers->finish();
     }

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -63,6 +64,12 @@ struct PerDevice {
     size_t shard_values = 0;
     ncclComm_t comm = nullptr;
     bool peer_ok = false;  // device 0 may read this device's memory (hipMemcpyPeerAsync path)
+    // kept across calls: this device's copy of the scene (while the caller keeps handing in the same tables: `scene_key`
+    // is a hash of their contents), a block for the counters and the two events that time the launch
+    RtScene* scene = nullptr;
+    uint64_t scene_key = 0;
+    RtStats* d_stats = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
 };
 struct Multi {
     uint32_t n = 0;
@@ -84,6 +91,10 @@ void multi_release_locked() {
     for (uint32_t d = 0; d < m.dev.size(); ++d) {
         if (hipSetDevice((int)(d % m.n_physical)) != hipSuccess) continue;
         PerDevice& p = m.dev[d];
+        if (p.scene) rt_hip_scene_destroy(p.scene);
+        if (p.d_stats) (void)hipFree(p.d_stats);
+        if (p.e0) (void)hipEventDestroy(p.e0);
+        if (p.e1) (void)hipEventDestroy(p.e1);
         if (p.comm && rccl().ok) (void)rccl().CommDestroy(p.comm);
         if (p.stream) (void)hipStreamDestroy(p.stream);
         rth::block_free(p.shard);
@@ -149,6 +160,59 @@ int grow(double** p, size_t* have, size_t want) {
     return RT_OK;
 }
 
+// A 64-bit hash of everything a scene's tables say (counts and contents): a device keeps its copy of the scene while the
+// caller keeps handing in the same tables (a fly-through, a re-render: the camera is not part of it).  8 bytes a step,
+// ~1 ms for the 4 MB of a 10 000-primitive scene, against 6 ms per device to validate, lay out and upload them again.
+uint64_t hash_bytes(uint64_t h, const void* p, size_t n) {
+    const unsigned char* b = static_cast<const unsigned char*>(p);
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        uint64_t w;
+        std::memcpy(&w, b + i, 8);
+        h = (h ^ w) * 0x9E3779B97F4A7C15ull;
+        h ^= h >> 29;
+    }
+    for (; i < n; ++i) h = (h ^ b[i]) * 0x100000001B3ull;
+    return h;
+}
+uint64_t scene_key_of(const RtSceneDesc& d) {
+    uint64_t h = 0xCBF29CE484222325ull;
+    auto table = [&](uint32_t n, const void* p, size_t each) {
+        h = hash_bytes(h, &n, sizeof n);
+        if (n && p) h = hash_bytes(h, p, (size_t)n * each);
+    };
+    table(d.n_shapes, d.shapes, sizeof(RtShape)), table(d.n_conics, d.conics, sizeof(RtConic));
+    table(d.n_triangles, d.triangles, sizeof(RtTriangle)), table(d.n_groups, d.groups, sizeof(RtGroup));
+    table(d.n_csgs, d.csgs, sizeof(RtCsg)), table(d.n_lhit, d.lhit, 1), table(d.n_materials, d.materials, sizeof(RtMaterial));
+    table(d.n_patterns, d.patterns, sizeof(RtPattern)), table(d.n_lights, d.lights, sizeof(RtLight));
+    table(d.n_bvh_nodes, d.bvh_nodes, sizeof(RtBvhNode)), table(d.n_dir_cands, d.dir_cands, sizeof(RtDirCand));
+    h = hash_bytes(h, &d.world_bvh_root, sizeof d.world_bvh_root), h = hash_bytes(h, &d.dir_res, sizeof d.dir_res);
+    if (d.dir_cell_start) {
+        table((uint32_t)((size_t)6 * d.dir_res * d.dir_res + 1), d.dir_cell_start, sizeof(uint32_t));
+        table(d.n_dir_entries, d.dir_entries, sizeof(uint32_t));
+    }
+    return h | 1ull;  // (0 = no scene kept)
+}
+
+// Where the device threads of one call agree on how the call goes on: every thread arrives once with its own outcome so
+// far, and all leave knowing whether EVERY device got that far.  The gather is a collective -- device 0 posts a receive
+// per peer, every peer a send -- so a device that failed before it (out of memory, a refused launch) must keep ALL the
+// others from entering it: a receive whose send never comes blocks device 0's stream for good.
+struct Gate {
+    std::mutex m;
+    std::condition_variable cv;
+    uint32_t n, arrived = 0;
+    bool all_ok = true;
+    explicit Gate(uint32_t n_) : n(n_) {}
+    bool arrive(bool ok) {
+        std::unique_lock<std::mutex> lock(m);
+        all_ok = all_ok && ok;
+        if (++arrived == n) cv.notify_all();
+        else cv.wait(lock, [this] { return arrived == n; });
+        return all_ok;
+    }
+};
+
 // rows of part `part` when the frame's `vsize` rows are dealt in bands of `band_rows` to `n` parts (RowMap's layout)
 uint32_t rows_of_part(uint32_t vsize, uint32_t band_rows, uint32_t n, uint32_t part) {
     const uint32_t n_bands = (vsize + band_rows - 1u) / band_rows;
@@ -213,64 +277,74 @@ extern "C" int rt_hip_render_multi(const RtSceneDesc* desc, const RtCameraDesc* 
     std::vector<int> result(n, RT_OK);
     std::vector<std::string> hip_text(n);
     std::vector<RtStats> dev_stats(n);
-    std::vector<RtScene*> scenes(n, nullptr);
+    const uint64_t key = scene_key_of(*desc);
+    Gate enqueued(n);
+    // RT_HIP_MULTI_FAIL_DEVICE=d (test knob): logical device d reports RT_ERR_INVALID_ARG instead of launching
+    const char* fail_env = std::getenv("RT_HIP_MULTI_FAIL_DEVICE");
+    const long fail_device = fail_env && *fail_env ? std::atol(fail_env) : -1;
     auto device_work = [&](uint32_t d) {
-        auto body = [&]() -> int {
+        PerDevice& p = m.dev[d];
+        bool launched = false;
+        // up to the launch: whatever goes wrong here, the thread still arrives at the gate
+        auto enqueue = [&]() -> int {
             HIP_TRY(hipSetDevice((int)(d % n_physical)));
-            PerDevice& p = m.dev[d];
-            int r = rt_hip_scene_create(desc, &scenes[d]);
+            if ((long)d == fail_device) return RT_ERR_INVALID_ARG;
+            if (p.scene && p.scene_key != key) {
+                rt_hip_scene_destroy(p.scene);
+                p.scene = nullptr, p.scene_key = 0;
+            }
+            if (!p.scene) {
+                const int r = rt_hip_scene_create(desc, &p.scene);
+                if (r != RT_OK) return r;
+                p.scene_key = key;
+            }
+            int r = grow(&p.shard, &p.shard_values, (size_t)part_rows[d] * row_values);
             if (r != RT_OK) return r;
-            if ((r = grow(&p.shard, &p.shard_values, (size_t)part_rows[d] * row_values)) != RT_OK) return r;
-            RtStats* d_stats = nullptr;
             if (stats) {
-                HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_stats), sizeof(RtStats)));
-                HIP_TRY(hipMemsetAsync(d_stats, 0, sizeof(RtStats), p.stream));
+                if (!p.d_stats) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p.d_stats), sizeof(RtStats)));
+                if (!p.e0) HIP_TRY(hipEventCreate(&p.e0));
+                if (!p.e1) HIP_TRY(hipEventCreate(&p.e1));
+                HIP_TRY(hipMemsetAsync(p.d_stats, 0, sizeof(RtStats), p.stream));
+                HIP_TRY(hipEventRecord(p.e0, p.stream));
             }
-            hipEvent_t e0 = nullptr, e1 = nullptr;
-            if (stats) {
-                HIP_TRY(hipEventCreate(&e0));
-                HIP_TRY(hipEventCreate(&e1));
-                HIP_TRY(hipEventRecord(e0, p.stream));
-            }
-            r = rt_hip_render_rows(scenes[d], cam, depth, d, n, band_rows, part_rows[d], p.shard, p.stream, d_stats);
-            if (r == RT_OK && stats) HIP_TRY(hipEventRecord(e1, p.stream));
-            // the gather: peers send their shard, device 0 receives them all, peer after peer, in one group
-            if (r == RT_OK && n > 1 && m.use_rccl) {
-                const Rccl& R = rccl();
-                ncclResult_t q = R.GroupStart();
-                if (d != 0) {
-                    if (q == ncclSuccess) q = R.Send(p.shard, (size_t)part_rows[d] * row_values, ncclDouble, 0, p.comm, p.stream);
-                } else {
-                    size_t at = 0;
-                    for (uint32_t peer = 1; peer < n && q == ncclSuccess; ++peer) {
-                        const size_t count = (size_t)part_rows[peer] * row_values;
-                        q = R.Recv(m.landing + at, count, ncclDouble, (int)peer, p.comm, p.stream);
-                        at += count;
-                    }
-                }
-                const ncclResult_t qe = R.GroupEnd();
-                if (q == ncclSuccess) q = qe;
-                if (q != ncclSuccess) r = fail_text(std::string("RCCL gather: ") + R.GetErrorString(q));
-            }
-            if (r == RT_OK) {
-                const hipError_t e = hipStreamSynchronize(p.stream);
-                if (e != hipSuccess) r = rth::hip_fail(e, "hipStreamSynchronize(device stream)");
-            }
-            if (r == RT_OK) r = rt_hip_scene_status(scenes[d], p.stream);
-            if (stats) {
-                if (r == RT_OK || r == RT_ERR_LIST_OVERFLOW || r == RT_ERR_NAN_T) {
-                    (void)hipMemcpy(&dev_stats[d], d_stats, sizeof(RtStats), hipMemcpyDeviceToHost);
-                    float ms = 0.f;
-                    if (e0 && e1 && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) dev_stats[d].kernel_ms = ms;
-                }
-                if (e0) (void)hipEventDestroy(e0);
-                if (e1) (void)hipEventDestroy(e1);
-                if (d_stats) (void)hipFree(d_stats);
-            }
+            launched = true;
+            r = rt_hip_render_rows(p.scene, cam, depth, d, n, band_rows, part_rows[d], p.shard, p.stream, stats ? p.d_stats : nullptr);
+            if (r == RT_OK && stats) HIP_TRY(hipEventRecord(p.e1, p.stream));
             return r;
         };
-        result[d] = body();
-        if (result[d] == RT_ERR_HIP) hip_text[d] = rt_hip_last_hip_error();
+        int r = enqueue();
+        const bool everyone = enqueued.arrive(r == RT_OK);
+        // the gather: peers send their shard, device 0 receives them all, peer after peer, in one group -- entered by all
+        // devices or by none
+        if (everyone && n > 1 && m.use_rccl) {
+            const Rccl& R = rccl();
+            ncclResult_t q = R.GroupStart();
+            if (d != 0) {
+                if (q == ncclSuccess) q = R.Send(p.shard, (size_t)part_rows[d] * row_values, ncclDouble, 0, p.comm, p.stream);
+            } else {
+                size_t at = 0;
+                for (uint32_t peer = 1; peer < n && q == ncclSuccess; ++peer) {
+                    const size_t count = (size_t)part_rows[peer] * row_values;
+                    q = R.Recv(m.landing + at, count, ncclDouble, (int)peer, p.comm, p.stream);
+                    at += count;
+                }
+            }
+            const ncclResult_t qe = R.GroupEnd();
+            if (q == ncclSuccess) q = qe;
+            if (q != ncclSuccess) r = fail_text(std::string("RCCL gather: ") + R.GetErrorString(q));
+        }
+        if (launched) {  // (also when another device failed: nothing of this call may still be running when it returns)
+            const hipError_t e = hipStreamSynchronize(p.stream);
+            if (e != hipSuccess && r == RT_OK) r = rth::hip_fail(e, "hipStreamSynchronize(device stream)");
+            if (r == RT_OK) r = rt_hip_scene_status(p.scene, p.stream);
+        }
+        if (stats && launched && (r == RT_OK || r == RT_ERR_LIST_OVERFLOW || r == RT_ERR_NAN_T)) {
+            (void)hipMemcpy(&dev_stats[d], p.d_stats, sizeof(RtStats), hipMemcpyDeviceToHost);
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) dev_stats[d].kernel_ms = ms;
+        }
+        result[d] = r;
+        if (r == RT_ERR_HIP) hip_text[d] = rt_hip_last_hip_error();
     };
     {
         std::vector<std::thread> threads;
@@ -317,11 +391,6 @@ extern "C" int rt_hip_render_multi(const RtSceneDesc* desc, const RtCameraDesc* 
         const int frc = finish();
         if (frc != RT_OK) rc = frc;
     }
-    for (uint32_t d = 0; d < n; ++d)
-        if (scenes[d]) {
-            (void)hipSetDevice((int)(d % n_physical));
-            rt_hip_scene_destroy(scenes[d]);
-        }
     if (stats) {  // counters add up over the devices; the kernel time is the slowest device's
         std::memset(stats, 0, sizeof *stats);
         static_assert(sizeof(RtStats) % sizeof(uint64_t) == 0, "RtStats is a row of 64-bit counters and one double");

@@ -79,7 +79,7 @@ enum {
     ST_RAY_PRIMARY = 0, ST_RAY_SHADOW, ST_RAY_REFLECT, ST_RAY_REFRACT,
     ST_PRIM0,  // .. ST_PRIM0 + 6
     ST_RAY_XFORM = ST_PRIM0 + 7, ST_GATES, ST_BVH_BOX, ST_HITS_SHADED, ST_NORMAL_LEVELS, ST_LIGHTINGS, ST_POW,
-    ST_PATTERN_NODES, ST_CONTAINER_PASSES, ST_LIST_ENTRIES, ST_SCHLICK, ST_COUNT
+    ST_PATTERN_NODES, ST_CONTAINER_PASSES, ST_LIST_ENTRIES, ST_SCHLICK, ST_ACCEL_F32, ST_COUNT
 };
 #define RT_STATUS_LIST_OVERFLOW (1u << 6)  // 1 << -RT_ERR_LIST_OVERFLOW
 #define RT_STATUS_NAN_T (1u << 7)          // 1 << -RT_ERR_NAN_T
@@ -259,6 +259,10 @@ RT_DEV void prim_intersect_rec(const double* __restrict__ inv, unsigned kf, cons
 // An OBJ mesh is thousands of triangles with this transform (obj.rs: parse_file): the teapot's leaf tests read 72 bytes
 // of triangle instead of 96 of matrix and 72 of triangle.
 #define RT_FLAG_IDENTITY (1u << 16)  // kind_flags, set by the library in its own copy of the tables (rt_hip_scene_create)
+// A CSG node one of whose RIGHT operand's primitives counts as a left hit (l_hit = left.includes(shape) is structural
+// equality, compound.rs:154 / shape.rs:18-23: a copy of a left primitive sitting in the right operand): its right operand's
+// entries can pass the filter without any left entry, so the "no left entry, nothing passes" shortcut does not hold for it.
+#define RT_FLAG_CSG_RIGHT_LHIT (1u << 17)
 RT_DEV Ray identity_ray(const Ray& r) {
     const bool all_neg = __builtin_signbit(r.d.x) && __builtin_signbit(r.d.y) && __builtin_signbit(r.d.z);
     const double z = all_neg ? -0.0 : 0.0;
@@ -528,10 +532,13 @@ RT_DEV int list_eval_core(const SceneDev& S, SW& W, int begin, int end, int leve
             // The right operand of an intersection or a difference whose LEFT operand has put nothing on the node's list: no
             // left entry means in_l never turns true, and without it (l_hit && ..) || (!l_hit && in_l) passes no entry of
             // either operand (compound.rs:142-181) -- the right operand need not be evaluated.  (Entries beyond `bound` are
-            // not on the list, and need not be: toggles there do not reach the entries before them.)
+            // not on the list, and need not be: toggles there do not reach the entries before them.)  Not for a node whose
+            // right operand holds a primitive that counts as a LEFT hit (RT_FLAG_CSG_RIGHT_LHIT): its entries are "left entries".
             if (level > floor && top == base && s > W.fnode[level] + 1) {  // (level > floor: inside a compound this walk entered)
                 const RtShape* __restrict__ gs = S.shapes + W.fnode[level];
-                if (RT_KIND(gs->kind_flags) == RT_CSG && ((gs->kind_flags >> RT_FLAG_CSG_OP_SHIFT) & 3u) != 0u) s = -2;
+                if (RT_KIND(gs->kind_flags) == RT_CSG && ((gs->kind_flags >> RT_FLAG_CSG_OP_SHIFT) & 3u) != 0u &&
+                    !(gs->kind_flags & RT_FLAG_CSG_RIGHT_LHIT))
+                    s = -2;
             }
         }
         if (s == -2) continue;  // (skipped: on to whatever comes after it on this level -- nothing, for a CSG node)

@@ -547,7 +547,7 @@ __global__ __launch_bounds__(64, RT_WF2_TRACE_WAVES) void wf2_trace_kernel(const
                     } else {
                         const float reach = fmaxf(fmaxf(fabsf((float)ray.o.x), fabsf((float)ray.o.y)), fabsf((float)ray.o.z)) * 1.000001f + A.extent_max;
                         worth = leaf_may_hit(A.pre + s, ray, reach, anc0, anc1);
-                        count(cx, ST_BVH_BOX);  // one more acceleration-only test
+                        count(cx, ST_ACCEL_F32);  // one more acceleration-only test
                     }
                 }
                 if (worth) {

@@ -1,9 +1,17 @@
-"""Counted FP64 FLOP budget of one render.
+"""Counted FLOP budget of one render.
 
 The counting variant of the render kernel tallies events (RtStats); each event has a fixed
 FP64 cost derived from the reference source (add/sub/mul/div/sqrt = 1; neg/abs/min/max/compare
 = 0).  `pow` is tallied separately and folded in at a nominal 60.  Acceleration-structure box
 tests are work this implementation adds and are priced like the reference's slab test.
+
+Two numerators, kept apart (most box tests of the large-scene kernels are f32):
+  algorithmic_flops(stats)   FP64 work -- everything the reference's arithmetic asks for plus the f64 box
+                             tests of the skip-link hierarchies (`bvh_box_tests`); priced against the FP64
+                             vector peak;
+  accel_f32_flops(stats)     the f32 tests of the 4-wide hierarchy (`accel_f32_tests`: four child boxes per
+                             node visited, one pre-test per leaf), at the same 12 per test; priced against
+                             the FP32 vector peak.  They are NOT part of the FP64 fraction.
 """
 
 COST = {
@@ -46,9 +54,15 @@ def algorithmic_flops(stats):
     return f
 
 
+def accel_f32_flops(stats):
+    """f32 operations of the 4-wide hierarchy's box tests and leaf pre-tests (acceleration only)."""
+    return COST["slab_test"] * stats.get("accel_f32_tests", 0)
+
+
 # MI355X FP64 vector peak: 256 CU x 4 SIMD x 16 FP64 lanes/clk x 2 (FMA) x 2.4 GHz
 # (= half the 157.3 TFLOP/s FP32 vector figure of MI355X_MICROARCH.md).  The path is
 # compiled with -ffp-contract=off (the reference never fuses a*b+c), so MUL and ADD issue
 # separately and the attainable ceiling is half of that.
 PEAK_FP64_VALU_TFLOPS = 78.6
 PEAK_FP64_VALU_NO_FMA_TFLOPS = 39.3
+PEAK_FP32_VALU_TFLOPS = 157.3

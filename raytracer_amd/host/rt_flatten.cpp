@@ -117,19 +117,37 @@ ABox primitive_box(const Primitive& p, const Matrix4& to_target) {
 // of the line: the argument needs "no entries", not "inside".  The geometric intersection of the operands' boxes would
 // NOT do: a left hit far outside the right operand's box passes the filter once in_r is stuck.)
 // csg.rs: tricylinder 2.2^3 -> one cylinder's box, ball 5.7 x 2 x 5.7 -> the sphere's box, hollowed_box 2.8^3 -> 2^3.
+// "Left entries" are the entries with l_hit = left.includes(shape) -- STRUCTURAL equality (shape.rs:18-23, Q7), not "sits in
+// the left operand": a primitive of the right operand that equals one of the left operand's counts as a left hit, and a
+// primitive of the left operand with an infinite bound (never equal to itself, Q7) counts as a right one.  So
+//   the LEFT operand's box holds only if no primitive of the right operand is a left hit (else right entries alone can pass);
+//   the RIGHT operand's box (intersection) holds only if every primitive of the left operand is a left hit (else left
+//   entries alone can toggle in_r and let the others through);
+// a node for which neither holds keeps the union of both boxes.
+bool any_included(const Shape& left, const Shape& s) {
+    if (s.is_primitive()) return left.includes(s.primitive());
+    for (const Shape& child : s.compound().children())
+        if (any_included(left, child)) return true;
+    return false;
+}
+bool all_included(const Shape& left, const Shape& s) {
+    if (s.is_primitive()) return left.includes(s.primitive());
+    for (const Shape& child : s.compound().children())
+        if (!all_included(left, child)) return false;
+    return true;
+}
 ABox tight_box(const Shape& s, const Matrix4& to_target) {
     if (s.is_primitive()) return primitive_box(s.primitive(), to_target);
     const Compound& c = s.compound();
     const Matrix4 m = to_target * c.properties().transform;
     if (c.kind() == Compound::Kind::Csg && c.operation() != Operation::Union) {
         const ABox l = tight_box(c.children()[0], m), r = tight_box(c.children()[1], m);
-        if (c.operation() == Operation::Difference) {
-            if (!l.empty() || l.unbounded) return l;
-        } else if (!l.empty() && !r.empty()) {
-            if (l.unbounded) return r;
-            if (r.unbounded) return l;
-            return l.half_area() <= r.half_area() ? l : r;
-        }
+        const bool left_ok = !any_included(c.children()[0], c.children()[1]) && !l.unbounded && !l.empty();
+        const bool right_ok = c.operation() == Operation::Intersection && all_included(c.children()[0], c.children()[0]) &&
+                              !r.unbounded && !r.empty();
+        if (left_ok && right_ok) return l.half_area() <= r.half_area() ? l : r;
+        if (left_ok) return l;
+        if (right_ok) return r;
         ABox b = l;
         b.merge(r);
         return b;

@@ -372,6 +372,27 @@ for name, w, h in (("cover", 203, 117), ("synthetic", 256, 150)):
         got, stn = cam.render_multi(world, n, stats=True)
         assert np.array_equal(got.pixels, ref.pixels), (name, n)
         assert stn.rays_primary == st.rays_primary and stn.hits_shaded == st.hits_shaded, (name, n)
+# a device that fails before the gather: every device skips the gather and the call returns that device's error (a
+# receive posted for a send that never comes would block device 0 for good); the next call is a normal one again, and
+# the devices' resident copies of the scene are reused (same tables) or replaced (other tables)
+import ctypes as C, os, time
+from raytracer_amd import _native as N
+world, cam = rt.synthetic(203, 117, 1500)
+ref = cam.render(world).pixels
+flat, cd = world.flatten(), cam.desc()
+out = np.empty((117, 203, 3))
+for bad in (0, 2, 3):
+    os.environ["RT_HIP_MULTI_FAIL_DEVICE"] = str(bad)
+    t0 = time.time()
+    rc = N.hip.rt_hip_render_multi(flat.desc, C.byref(cd), 5, 4, out.ctypes.data_as(C.POINTER(C.c_double)), None)
+    assert rc == N.RT_ERR_INVALID_ARG and time.time() - t0 < 20, (bad, rc)
+del os.environ["RT_HIP_MULTI_FAIL_DEVICE"]
+for _ in range(2):
+    out[:] = -1
+    assert N.hip.rt_hip_render_multi(flat.desc, C.byref(cd), 5, 4, out.ctypes.data_as(C.POINTER(C.c_double)), None) == 0
+    assert np.array_equal(out, ref)
+world2, cam2 = rt.exercise("cover", 203, 117)
+assert np.array_equal(cam2.render_multi(world2, 4).pixels, cam2.render(world2).pixels)
 print("ok")
 '''
     env = dict(os.environ, RT_HIP_MULTI_ALIAS="1", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -419,3 +440,52 @@ def test_pipeline_containers_deeper_than_four():
     ref, _ = orc.OracleWorld(world.describe()).render(cam)
     compare("glass-shells", two, ref)
     scene.close()
+
+
+def _structural_csg_world():
+    """CSG nodes whose l_hit = left.includes(shape) (compound.rs:154: structural equality, shape.rs:18-23) does not follow
+    the operands: a copy of the left sphere sitting in the right operand counts as a LEFT hit, a plane in the left operand
+    (never equal to itself: its bounds are infinite) as a RIGHT one.  The reference then reports hits the 'no left entry,
+    nothing passes' shortcuts would drop: hits of the displaced copy on rays that miss the left sphere, hits of the left
+    sphere on rays that miss the right cube."""
+    from raytracer_amd import Material, Matrix, PointLight, Primitive, World
+    red, green, blue = Material(color=(0.9, 0.2, 0.2)), Material(color=(0.2, 0.9, 0.2)), Material(color=(0.2, 0.3, 0.9), reflective=0.2)
+    ball = lambda m: Primitive.new_sphere().with_material(m)
+    # difference(S, group(translate 5){S})
+    a = rt.Compound.new_csg(rt.Operation.Difference, ball(red),
+                            rt.Compound.new_group([ball(red)]).with_transform(Matrix.translation(3.0, 0.0, 0.0)))
+    # intersection(S, group(translate){S, cube})
+    b = rt.Compound.new_csg(rt.Operation.Intersection, ball(green),
+                            rt.Compound.new_group([ball(green), Primitive.new_cube().with_transform(Matrix.scaling(0.6, 0.6, 0.6))])
+                            .with_transform(Matrix.translation(0.0, 2.6, 0.0))).with_transform(Matrix.translation(-4.0, 0.0, 0.0))
+    # intersection(group{sphere, plane}, cube): the plane's entries toggle in_r
+    c = rt.Compound.new_csg(rt.Operation.Intersection,
+                            rt.Compound.new_group([ball(blue), Primitive.new_plane().with_transform(Matrix.translation(0.0, -0.3, 0.0))]),
+                            Primitive.new_cube().with_transform(Matrix.chain(Matrix.translation(2.5, 0.0, 0.0), Matrix.scaling(0.5, 0.5, 0.5)))
+                            ).with_transform(Matrix.translation(0.0, 0.0, 5.0))
+    floor = Primitive.new_plane().with_transform(Matrix.translation(0.0, -3.0, 0.0)).with_material(Material(color=(0.7, 0.7, 0.7)))
+    world = World([a, b, c, floor], [PointLight((-6.0, 9.0, -10.0), (1.0, 1.0, 1.0))])
+    cam = rt.Camera(320, 200, 1.1).with_transform(Matrix.view_transform((0.5, 2.0, -11.0), (0.0, 0.5, 1.0), (0.0, 1.0, 0.0)))
+    return world, cam
+
+
+@pytest.mark.parametrize("hierarchy", [True, False, "nested", "global"])
+def test_csg_left_hits_are_structural(hierarchy):
+    """the right operand is skipped / a CSG node takes one operand's box only when no primitive of the right
+    operand is a left hit (and, for the right operand's box, every primitive of the left operand is one)."""
+    world, cam = _structural_csg_world()
+    ow = orc.OracleWorld(world.describe())
+    ref, _ = ow.render(cam)
+    flat = world.flatten(hierarchy)
+    scene = rt.DeviceScene(flat)
+    gpu = _render_resident(scene, cam, 0)
+    compare(f"structural-csg-{hierarchy}", gpu, ref)
+    scene.close()
+    # the displaced copies are really seen (the shortcut would have dropped them): rays aimed at them hit something
+    rays = np.array([[3.0, 0.0, -10.0, 0.0, 0.0, 1.0],      # the copy of a's sphere, 3 to the right: misses the left sphere
+                     [-4.0, 2.6, -10.0, 0.0, 0.0, 1.0],     # b's displaced group
+                     [0.0, 0.5, -10.0, 0.0, 0.0, 1.0]])     # c's sphere above its plane, far from the cube
+    got, want = world.probe(rays), ow.probe(rays)
+    assert np.array_equal(got[:, [0, 2]], want[:, [0, 2]])
+    assert not rel_mismatch(got, want, 1e-12, 1e-15).any()
+    assert (want[:, 0] >= 0).any()

@@ -265,6 +265,35 @@ def test_csg_box_is_the_operand_whose_absence_empties_the_node():  # compound.rs
             assert create(flat.desc) in (N.RT_OK, N.RT_ERR_NO_DEVICE)
 
 
+def test_csg_box_keeps_both_operands_when_left_hits_are_not_the_left_operand():  # compound.rs:154, shape.rs:18-23
+    # l_hit is structural equality: a copy of the left sphere inside the right operand counts as a LEFT hit (its entries
+    # pass a difference on a ray that misses the left sphere), a plane or an unbounded cylinder in the left operand (never
+    # equal to itself, Q7) as a RIGHT one (its entries toggle in_r).  Such nodes keep the union of both operands' boxes.
+    ball = Primitive.new_sphere()
+    other = Primitive.new_sphere().with_transform(Matrix.translation(0, 9, 0))
+    moved = rt.Compound.new_group([Primitive.new_sphere()]).with_transform(Matrix.translation(5, 0, 0))
+    d = World([rt.Compound.new_csg(Operation.Difference, ball, moved), other], []).flatten().desc.contents
+    bmin, bmax = _world_leaf_box(d, 0)
+    assert bmin[0] <= -1 and bmax[0] >= 6, (bmin, bmax)
+    # (an intersection may still take the RIGHT operand's box here: a line that misses it meets left entries only, all of
+    # them left hits, and nothing toggles in_r)
+    d = World([rt.Compound.new_csg(Operation.Intersection, ball, moved), other], []).flatten().desc.contents
+    bmin, bmax = _world_leaf_box(d, 0)
+    assert bmin[0] >= 3.9 and bmax[0] >= 6, (bmin, bmax)
+    # a cylinder without limits in the left operand: the (smaller) right operand's box does not bound an intersection
+    left = rt.Compound.new_group([Primitive.new_sphere().with_transform(Matrix.scaling(3, 3, 3)),
+                                  Primitive.new_cylinder(rt.Conic(-np.inf, 2.0, False))])
+    cube = Primitive.new_cube().with_transform(Matrix.chain(Matrix.translation(2.5, 0, 0), Matrix.scaling(0.5, 0.5, 0.5)))
+    d = World([rt.Compound.new_csg(Operation.Intersection, left, cube), other], []).flatten().desc.contents
+    found = [k for k in range(d.n_bvh_nodes) if d.bvh_nodes[k].shape == 0]
+    assert found and not np.isfinite(list(d.bvh_nodes[found[0]].bmin)).all()  # unbounded: always visited
+    # the same node with a bounded left operand keeps the smaller operand's box
+    left2 = rt.Compound.new_group([Primitive.new_sphere().with_transform(Matrix.scaling(3, 3, 3))])
+    d = World([rt.Compound.new_csg(Operation.Intersection, left2, cube), other], []).flatten().desc.contents
+    bmin, bmax = _world_leaf_box(d, 0)
+    assert bmin[0] >= 1.9 and bmax[0] <= 3.1
+
+
 def test_group_inside_csg_gets_a_hierarchy_only_without_conics():
     # a cylinder or cone can return a hit outside its box (primitive.rs:486-490); the direction index makes up for
     # that for whole CSG nodes, not inside one

@@ -59,3 +59,31 @@ def test_noalloc_refuses_a_frame_too_wide_for_its_workspace():
     rc = N.hip.rt_hip_render_rows_noalloc(scene._p, C.byref(cd), 5, 0, 1, 8, 8, C.c_void_p(out.data_ptr()), None, None)
     assert rc == N.RT_ERR_NOALLOC_SIZE
     assert b"too wide" in N.hip.rt_hip_strerror(rc)
+
+
+def test_noalloc_with_three_lights():
+    """The workspace holds one occlusion byte per light and hit, so the number of lights decides how many rows fit a batch
+    (the synthetic scene above has cover.rs's two lights): 260 primitives in 13 groups under three lights."""
+    from raytracer_amd import Material, Matrix, PointLight, Primitive, World
+    rng = np.random.default_rng(17)
+    groups = []
+    for g in range(13):
+        prims = []
+        for i in range(20):
+            kind = [Primitive.new_sphere, Primitive.new_cube][i % 2]
+            p = rng.uniform(-1.5, 1.5, 3)
+            s = rng.uniform(0.15, 0.4)
+            prims.append(kind().with_transform(Matrix.chain(Matrix.translation(p[0], p[1], p[2]), Matrix.scaling(s, s, s)))
+                         .with_material(Material(color=tuple(rng.uniform(0.2, 0.9, 3)), reflective=0.4 if i % 4 == 0 else 0.0,
+                                                 transparency=0.6 if i % 7 == 0 else 0.0, refractive_index=1.4)))
+        groups.append(rt.Compound.new_group(prims).with_transform(
+            Matrix.chain(Matrix.translation(4.0 * (g % 5) - 8.0, 1.6, 4.0 * (g // 5)), Matrix.rotation_y(0.3 * g))))
+    floor = Primitive.new_plane().with_material(Material(color=(0.8, 0.8, 0.75), reflective=0.15))
+    world = World(groups + [floor], [PointLight((-10, 12, -10), (0.6, 0.6, 0.6)), PointLight((9, 7, -6), (0.3, 0.3, 0.4)),
+                                    PointLight((0, 15, 12), (0.3, 0.2, 0.2))])
+    cam = rt.Camera(400, 225, 1.0).with_transform(Matrix.view_transform((0, 6, -16), (0, 1, 3), (0, 1, 0)))
+    scene = rt.DeviceScene(world.flatten("global"))
+    scene.set_wavefront(2)
+    assert "pipeline" in scene.pipeline_name(5)
+    _both(scene, cam)
+    _both(scene, cam, parts=((2, 3),))
