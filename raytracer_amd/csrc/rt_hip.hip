@@ -690,7 +690,10 @@ int rt_hip_scene_create(const RtSceneDesc* desc, RtScene** out) {
         if (!is_flat)
             bytes += sizeof(RtGroup) * desc->n_groups + sizeof(RtCsg) * desc->n_csgs + desc->n_lhit + sizeof(RtBvhNode) * desc->n_bvh_nodes +
                      sizeof(RtTriangle) * desc->n_triangles;
-        const bool may_fit = is_flat ? bytes <= RT_STAGE_MAX_BYTES && world_hits <= RT_LDS_LIST_CAP : bytes <= RT_STAGE_MAX_BYTES_COMPOUND;
+        bool may_fit = is_flat ? bytes <= RT_STAGE_MAX_BYTES && world_hits <= RT_LDS_LIST_CAP : bytes <= RT_STAGE_MAX_BYTES_COMPOUND;
+#ifdef RT_HOST_EMU  // (tests/emu runs a block's threads one after the other: no cooperative staging there)
+        may_fit = false;
+#endif
         if (may_fit) {  // (large scenes do not pay for an image they will not use)
             {  // (the library's copy: it carries RT_FLAG_IDENTITY)
                 const std::vector<unsigned char> mine(arena.host.begin() + (long)o_shapes,

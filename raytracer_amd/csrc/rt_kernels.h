@@ -67,7 +67,11 @@ __device__ void flush_stats(Ctx<STATS, FLAT>& cx, RtStats* __restrict__ stats, u
 // STAGED (FLAT scenes whose tables fit RT_STAGE_MAX_BYTES): the block first copies the packed
 // table image into LDS and shades out of that copy; the per-lane, dependent record reads of
 // prepare_computations / lighting / pattern evaluation then cost an LDS access, not an L2 one.
+#ifdef RT_HOST_EMU  // (tests/emu: the sources compiled for the host under sanitizers; staged scenes are not run there)
+inline __align__(16) unsigned char rt_lds[160u * 1024u];
+#else
 extern __shared__ __align__(16) unsigned char rt_lds[];
+#endif
 
 // RECURSE == false: no material of the scene reflects or transmits (world.rs:99,110 always take their
 // early exits), so the kernel is instantiated with a recursion budget of zero: no frames, no n1 / n2,
