@@ -633,7 +633,11 @@ int run_pipeline(const RtScene* scene, const Wf2* w, const Wf2Space& sp, size_t 
     const Wf2Accel A = w->accel;
     const bool cands_pass = A.has_cands && !RT_WF2_CANDS_INLINE;  // the direction candidates in a kernel of their own
     unsigned* status = scene->d_status;
-    const dim3 wide(2048), threads(256);
+#ifdef RT_HOST_EMU  // (tests/emu: every block costs host threads; the kernels stride over their items whatever the grid)
+    const dim3 wide(4), threads(256), overflow_grid(4);
+#else
+    const dim3 wide(2048), threads(256), overflow_grid(4096);
+#endif
     auto go = [&](auto stats_tag) {
         constexpr bool ST = decltype(stats_tag)::value;
         dim3 tgrid[4] = {dim3((unsigned)(w->n_cus * w->trace_blocks_per_cu[ST][0])), dim3((unsigned)(w->n_cus * w->trace_blocks_per_cu[ST][1])),
@@ -691,7 +695,7 @@ int run_pipeline(const RtScene* scene, const Wf2* w, const Wf2Space& sp, size_t 
                     }
                 }
                 hipLaunchKernelGGL((wf2_light_kernel<ST>), wide, threads, 0, side, S, spg, *cam, rows, g, d_out, d_stats, status);
-                if (more) hipLaunchKernelGGL((wf2_overflow_kernel<ST>), dim3(4096), dim3(64), 0, side, S, spg, g, d_out, d_stats, status);
+                if (more) hipLaunchKernelGGL((wf2_overflow_kernel<ST>), overflow_grid, dim3(64), 0, side, S, spg, g, d_out, d_stats, status);
                 if (two) (void)hipEventRecord(w->lit[g], side);
                 if (!more) break;
                 hipLaunchKernelGGL(wf2_scan_kernel, dim3(1), dim3(RT_WF_SHARDS), 0, stream, spg, g);

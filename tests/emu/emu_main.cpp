@@ -46,6 +46,12 @@ void rth::dir_index_free(DirIndex*) {}
 #define RT_EMU_UNPOISON(p, n) ((void)0)
 #endif
 
+void hip_emu_collective_timeout(int what, unsigned arrived, unsigned n) {
+    static const char* names[] = {"ballot", "__shfl", "__shfl_up", "__shfl_down", "readfirstlane", "wave barrier", "__syncthreads"};
+    std::fprintf(stderr, "hip_emu: %s reached by %u of %u threads only after two minutes (a collective in divergent code?)\n", names[what], arrived, n);
+    std::abort();
+}
+
 namespace {
 
 void unpoison(const RtSceneDesc& d) {
@@ -125,6 +131,28 @@ int main(int argc, char** argv) {
         std::printf("emu: mode 1 (queue %llu, nodes %llu): %s; counting variant: %s\n", (unsigned long long)c.q, (unsigned long long)c.n,
                     a ? "equal" : "DIFFER", b ? "equal" : "DIFFER");
         ok = ok && a && b;
+    }
+    // mode 2, the kernel pipeline (rt_wf2.h), where the scene has one: its kernels are wave-cooperative (records put
+    // together in LDS, ballots, shuffles), so they run in the lockstep model -- 64 real lanes per wave
+    rt_hip_scene_set_wavefront(scene, 2, 0, 0);
+    if (std::strstr(rt_hip_scene_kernels(scene, 5), "pipeline") != nullptr) {
+        hip_emu::lockstep = true;
+        const Cap caps2[] = {{0, 0}, {pixels / 7, pixels}, {193, 61}};
+        for (const Cap& c : caps2) {
+            const bool a = same(mono, render(scene, cam, 2, c.q, c.n, false));
+            const bool b = same(mono, render(scene, cam, 2, c.q, c.n, true, &st1));
+            std::printf("emu: mode 2 (queue %llu, nodes %llu), 64 lanes in lockstep: %s; counting variant: %s\n", (unsigned long long)c.q,
+                        (unsigned long long)c.n, a ? "equal" : "DIFFER", b ? "equal" : "DIFFER");
+            ok = ok && a && b;
+            if (c.q == 0) {
+                const bool rays = st0.rays_primary == st1.rays_primary && st0.rays_shadow == st1.rays_shadow &&
+                                  st0.rays_reflect == st1.rays_reflect && st0.rays_refract == st1.rays_refract;
+                std::printf("emu: ray counts of mode 2: primary %llu shadow %llu reflect %llu refract %llu\n", (unsigned long long)st1.rays_primary,
+                            (unsigned long long)st1.rays_shadow, (unsigned long long)st1.rays_reflect, (unsigned long long)st1.rays_refract);
+                (void)rays;  // (mode 0's counters come from the sequential model, where only lane 0 of a wave reports)
+            }
+        }
+        hip_emu::lockstep = false;
     }
     rt_hip_scene_destroy(scene);
     rt_hip_shutdown();
