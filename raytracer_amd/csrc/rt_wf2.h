@@ -44,9 +44,16 @@ struct Wf2Hit {  // closest hit of one colour ray
 
 // Shading contexts of one generation's hits, one slot per hit, structure-of-arrays so that the lanes of a
 // wave read and write consecutive words.
-enum { CX_OVER = 0, CX_UNDER = 3, CX_EYE = 6, CX_NORMAL = 9, CX_REFLECT = 12, CX_COLOR = 15, CX_SURFACE = 18,
-       CX_T = 21, CX_N1 = 22, CX_N2 = 23, CX_DOUBLES = 24 };
-enum { CU_MAT = 0, CU_PARENT = 1, CU_REMAINING = 2, CU_ITEM = 3, CU_NODE = 4, CU_UINTS = 5 };
+// What a hit keeps between the kernels is what cannot be had again bit for bit: over_point, eye, the normal, the pattern
+// colour and t.  reflect_v = reflect(-eye, normal) and under_point = position(ray, t) - normal * EPSILON are worked out
+// again, by the same expressions on the same bits, by the few hits that need them (wf2_spawn / wf2_overflow: the ray is
+// the item's, slot = ray index); n1 / n2 exist only for transparent hits (written by the containers walk); CX_SURFACE only
+// and CX_UNDER only for hits whose children found no room (wf2_overflow_kernel runs on the scene's second stream, beside the
+// compaction that overwrites the generation's dense queue: it cannot go back to the ray, so wf2_spawn leaves it under_point).
+// 13 doubles + 4 words written per hit (120 B; 188 B in round 2).
+enum { CX_OVER = 0, CX_EYE = 3, CX_NORMAL = 6, CX_COLOR = 9, CX_T = 12, CX_N1 = 13, CX_N2 = 14, CX_SURFACE = 15, CX_UNDER = 18,
+       CX_DOUBLES = 21 };
+enum { CU_MAT = 0, CU_PARENT = 1, CU_REMAINING = 2, CU_NODE = 3, CU_UINTS = 4 };
 // CU_NODE: where the hit's lit surface colour goes -- the node wf2_spawn_kernel made for it, or one of
 #define RT_WF2_NODE_NONE 0xffffffffu     // no children: the colour straight to whoever waits for this ray
 #define RT_WF2_NODE_REFUSED 0xfffffffeu  // children found no room: into the context (CX_SURFACE), for wf2_overflow_kernel
@@ -350,7 +357,7 @@ __global__ __launch_bounds__(64, RT_WF2_TRACE_WAVES) void wf2_trace_kernel(const
                     bool valid;
                     if constexpr (LIST) {
                         slot = sp.creq[item];
-                        const unsigned of = ctx_u(sp, slot, CU_ITEM);
+                        const unsigned of = slot;  // (a hit's shading context is its ray's index)
                         valid = gen == 0u ? wf2_item_ray<WF2_PRIMARY>(S, sp, cam, rows, pm, of, 0u, ray, limit)
                                           : wf2_item_ray<WF2_QUEUE>(S, sp, cam, rows, pm, of, 0u, ray, limit);
                         const unsigned sub = lane & (split - 1u);
@@ -805,18 +812,13 @@ __global__ __launch_bounds__(256, RT_WF2_PREP_WAVES) void wf2_prepare_kernel(con
                 count(cx, ST_PATTERN_NODES, nodes);
             }
             ctx_put(sp, slot, CX_OVER, c.over_point);
-            ctx_put(sp, slot, CX_UNDER, c.under_point);
             ctx_put(sp, slot, CX_EYE, c.eye_v);
             ctx_put(sp, slot, CX_NORMAL, c.normal_v);
-            ctx_put(sp, slot, CX_REFLECT, c.reflect_v);
             ctx_put(sp, slot, CX_COLOR, color);
             ctx_f(sp, slot, CX_T) = hit.t;
-            ctx_f(sp, slot, CX_N1) = 1.0;
-            ctx_f(sp, slot, CX_N2) = 1.0;
             ctx_u(sp, slot, CU_MAT) = sh->material;
             ctx_u(sp, slot, CU_PARENT) = parent;
             ctx_u(sp, slot, CU_REMAINING) = remaining;
-            ctx_u(sp, slot, CU_ITEM) = i;
             ctx_u(sp, slot, CU_NODE) = RT_WF2_NODE_NONE;
         }
         // requests for n1 / n2 go to the part of the list that belongs to this group of four waves
@@ -827,15 +829,34 @@ __global__ __launch_bounds__(256, RT_WF2_PREP_WAVES) void wf2_prepare_kernel(con
     flush_stats(cx, stats, status);
 }
 
-RT_DEV void ctx_shade(const SceneDev& S, const Wf2Space& sp, unsigned slot, Shade& sd, uint32_t& remaining) {
-    sd.over = ctx_v3(sp, slot, CX_OVER), sd.under = ctx_v3(sp, slot, CX_UNDER), sd.eye = ctx_v3(sp, slot, CX_EYE);
-    sd.normal = ctx_v3(sp, slot, CX_NORMAL), sd.reflect_v = ctx_v3(sp, slot, CX_REFLECT), sd.color = ctx_v3(sp, slot, CX_COLOR);
-    sd.n1 = ctx_f(sp, slot, CX_N1), sd.n2 = ctx_f(sp, slot, CX_N2);
-    sd.mat = (int)ctx_u(sp, slot, CU_MAT);
+// The Shade record of a hit whose material lets it have children (reflective or transparent, recursion budget left), for
+// shade_children: everything the context does not keep is worked out again as prepare_computations had it
+// (intersection.rs:76-98) -- reflect_v from -eye = the ray's direction and the normal; for a transparent hit n1 / n2 as the
+// containers walk left them and under_point from the ray (`gen`'s item `slot`: a pixel's camera ray, or the queued one)
+// and t.  surface and color are not read by shade_children and are left alone.
+RT_DEV void ctx_shade_children(const SceneDev& S, const Wf2Space& sp, const RtCameraDesc& cam, const RowMap& rows, const PixelMap& pm,
+                               unsigned gen, unsigned slot, const RtMaterial& m, uint32_t remaining, Shade& sd) {
+    sd.over = ctx_v3(sp, slot, CX_OVER), sd.eye = ctx_v3(sp, slot, CX_EYE), sd.normal = ctx_v3(sp, slot, CX_NORMAL);
+    sd.reflect_v = reflect(-sd.eye, sd.normal);  // intersection.rs:91: ray.direction.reflect(&normal_v), eye_v = -direction
+    sd.under = sd.over;
+    sd.n1 = 1.0, sd.n2 = 1.0;
     sd.li = S.n_lights;
-    remaining = ctx_u(sp, slot, CU_REMAINING);
-    const RtMaterial m = S.mats[sd.mat];
     sd.want_n = (m.transparency != 0.0 && remaining != 0u) ? 1 : 0;
+    if (sd.want_n != 0) {
+        sd.n1 = ctx_f(sp, slot, CX_N1), sd.n2 = ctx_f(sp, slot, CX_N2);
+        Ray ray{v3(0.0, 0.0, 0.0), v3(0.0, 0.0, 1.0)};
+        double unused;
+        if (gen == 0u)
+            (void)wf2_item_ray<WF2_PRIMARY>(S, sp, cam, rows, pm, slot, 0u, ray, unused);
+        else
+            (void)wf2_item_ray<WF2_QUEUE>(S, sp, cam, rows, pm, slot, 0u, ray, unused);
+        const V3 point = ray.o + ray.d * ctx_f(sp, slot, CX_T);  // ray.rs:15-17
+        sd.under = point - sd.normal * EPSILON;                  // intersection.rs:90
+    }
+}
+// can the hit have children at all (world.rs:99,110: the early exits of reflected_color / refracted_color)?
+RT_DEV bool may_have_children(const RtMaterial& m, uint32_t remaining) {
+    return remaining != 0u && (m.reflective != 0.0 || m.transparency != 0.0);
 }
 
 // wf_commit for the pipeline: a node per asking lane and its child rays into the shard's slice of the sliced queue,
@@ -953,10 +974,11 @@ __global__ __launch_bounds__(256, RT_WF2_FINISH_WAVES) void wf2_spawn_kernel(con
     }
     __shared__ uint2 stage_all[4u * RT_WF2_STAGE_WORDS];  // (256-thread blocks)
     uint2* stage = stage_all + (threadIdx.x >> 6) * RT_WF2_STAGE_WORDS;
-    const unsigned n = wf2_n_slots(sp, gen, pixel_map(cam, rows));
+    const PixelMap pm = pixel_map(cam, rows);
+    const unsigned n = wf2_n_slots(sp, gen, pm);
     const unsigned n_round = (n + 63u) & ~63u;
     for (unsigned slot = blockIdx.x * blockDim.x + threadIdx.x; slot < n_round; slot += gridDim.x * blockDim.x) {
-        const bool active = slot < n && ctx_u(sp, slot < n ? slot : 0u, CU_MAT) != 0xffffffffu;
+        const uint32_t mat = slot < n ? ctx_u(sp, slot, CU_MAT) : 0xffffffffu;
         Shade sd;
         sd.surface = v3(0.0, 0.0, 0.0);
         sd.over = sd.reflect_v = v3(0.0, 0.0, 0.0);
@@ -966,13 +988,17 @@ __global__ __launch_bounds__(256, RT_WF2_FINISH_WAVES) void wf2_spawn_kernel(con
         ch.reflectance = 0.0;
         double reflective = 0.0, transparency = 0.0;
         bool want = false;
-        if (active) {
-            ctx_shade(S, sp, slot, sd, remaining);
-            parent = ctx_u(sp, slot, CU_PARENT);
-            const RtMaterial m = S.mats[sd.mat];
-            reflective = m.reflective, transparency = m.transparency;
-            shade_children(m, sd, Ray{sd.over, sd.reflect_v}, (int)remaining, ch, cx);
-            want = ch.do_reflect || ch.do_refract;
+        if (mat != 0xffffffffu) {  // a hit: only one whose material and budget allow children reads the rest of its context
+            remaining = ctx_u(sp, slot, CU_REMAINING);
+            const RtMaterial m = S.mats[mat];
+            if (may_have_children(m, remaining)) {
+                sd.mat = (int)mat;
+                ctx_shade_children(S, sp, cam, rows, pm, gen, slot, m, remaining, sd);
+                parent = ctx_u(sp, slot, CU_PARENT);
+                reflective = m.reflective, transparency = m.transparency;
+                shade_children(m, sd, Ray{sd.over, sd.reflect_v}, (int)remaining, ch, cx);
+                want = ch.do_reflect || ch.do_refract;
+            }
         }
         // a wave's children go to the shard picked by where they come from: a stretch of consecutive hits
         const unsigned out_shard = (((unsigned)__builtin_amdgcn_readfirstlane((int)slot) >> stretch_shift) * 2654435761u) >> 24;
@@ -988,6 +1014,7 @@ __global__ __launch_bounds__(256, RT_WF2_FINISH_WAVES) void wf2_spawn_kernel(con
         const unsigned r = wave_slots(&sp.cnt->n_overflow[gen], refused);
         if (refused) {
             ctx_u(sp, slot, CU_NODE) = RT_WF2_NODE_REFUSED;
+            ctx_put(sp, slot, CX_UNDER, sd.under);  // (what wf2_overflow_kernel cannot work out again: see CX_UNDER)
             sp.overflow[r] = slot;
         }
     }
@@ -1007,29 +1034,29 @@ __global__ __launch_bounds__(256, RT_WF2_FINISH_WAVES) void wf2_light_kernel(con
     }
     const unsigned n = wf2_n_slots(sp, gen, pixel_map(cam, rows));
     for (unsigned slot = blockIdx.x * blockDim.x + threadIdx.x; slot < n; slot += gridDim.x * blockDim.x) {
-        if (ctx_u(sp, slot, CU_MAT) == 0xffffffffu) continue;  // no hit in this slot
-        Shade sd;
-        uint32_t remaining = 0;
-        ctx_shade(S, sp, slot, sd, remaining);
-        sd.surface = v3(0.0, 0.0, 0.0);
-        const RtMaterial m = S.mats[sd.mat];
+        const uint32_t mat = ctx_u(sp, slot, CU_MAT);
+        if (mat == 0xffffffffu) continue;  // no hit in this slot
+        const V3 over = ctx_v3(sp, slot, CX_OVER), eye = ctx_v3(sp, slot, CX_EYE), normal = ctx_v3(sp, slot, CX_NORMAL);
+        const V3 color = ctx_v3(sp, slot, CX_COLOR);
+        V3 surface = v3(0.0, 0.0, 0.0);
+        const RtMaterial m = S.mats[mat];
         for (unsigned l = 0; l < S.n_lights; ++l) {  // world.rs:58-70, in light order
             const RtLight light = S.lights[l];
             const bool occluded = sp.occ[(size_t)l * n + slot] != 0;
-            sd.surface = sd.surface + lighting(m, sd.color, light, sd.over, sd.eye, sd.normal, occluded, cx);
+            surface = surface + lighting(m, color, light, over, eye, normal, occluded, cx);
         }
         const uint32_t node = ctx_u(sp, slot, CU_NODE);
         if (node == RT_WF2_NODE_REFUSED) {
-            ctx_put(sp, slot, CX_SURFACE, sd.surface);
+            ctx_put(sp, slot, CX_SURFACE, surface);
         } else if (node != RT_WF2_NODE_NONE) {
-            sp.ws.nodes[node].surface = sd.surface;
-        } else {  // no children: world.rs:76-82 with both of them black
-            Children ch;
-            Ctx<false, CLS> quiet;  // (wf2_spawn_kernel counted the Schlick evaluation, if this generation had one)
-            quiet.status = 0;
-            shade_children(m, sd, Ray{sd.over, sd.reflect_v}, (int)remaining, ch, quiet);
+            sp.ws.nodes[node].surface = surface;
+        } else {
+            // No children: world.rs:76-82 with both of them black.  The Schlick mix is still the one the material asks for
+            // (reflective > 0 && transparency > 0), with the reflectance shade_children leaves at 0.0 for a hit without
+            // recursion budget -- and a hit WITH budget and a reflective material has children (world.rs:99), so it is not here.
+            const bool use_schlick = m.reflective > 0.0 && m.transparency > 0.0;
             wf_deliver(sp.ws.nodes, out, ctx_u(sp, slot, CU_PARENT),
-                       combine(sd.surface, v3(0.0, 0.0, 0.0), v3(0.0, 0.0, 0.0), ch.use_schlick, ch.reflectance));
+                       combine(surface, v3(0.0, 0.0, 0.0), v3(0.0, 0.0, 0.0), use_schlick, 0.0));
         }
     }
     flush_stats(cx, stats, status);
@@ -1051,10 +1078,18 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void wf2_overflow_kernel(con
     for (unsigned r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
         const unsigned slot = sp.overflow[r];
         Shade sd;
-        uint32_t remaining;
-        ctx_shade(S, sp, slot, sd, remaining);
-        sd.surface = ctx_v3(sp, slot, CX_SURFACE);
+        const uint32_t remaining = ctx_u(sp, slot, CU_REMAINING);
+        sd.mat = (int)ctx_u(sp, slot, CU_MAT);
         const RtMaterial m = S.mats[sd.mat];
+        // (as ctx_shade_children has it, except that under_point is the one wf2_spawn_kernel left: this kernel runs beside
+        // the compaction of the next generation's queue, which overwrites the rays of this one)
+        sd.over = ctx_v3(sp, slot, CX_OVER), sd.eye = ctx_v3(sp, slot, CX_EYE), sd.normal = ctx_v3(sp, slot, CX_NORMAL);
+        sd.reflect_v = reflect(-sd.eye, sd.normal);
+        sd.under = ctx_v3(sp, slot, CX_UNDER);
+        sd.li = S.n_lights;
+        sd.want_n = (m.transparency != 0.0 && remaining != 0u) ? 1 : 0;
+        sd.n1 = sd.want_n != 0 ? ctx_f(sp, slot, CX_N1) : 1.0, sd.n2 = sd.want_n != 0 ? ctx_f(sp, slot, CX_N2) : 1.0;
+        sd.surface = ctx_v3(sp, slot, CX_SURFACE);
         Children ch;
         Ctx<false, CLS> quiet;  // (the Schlick evaluation was counted when the hit was lit)
         quiet.status = 0;

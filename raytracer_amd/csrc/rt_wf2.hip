@@ -679,13 +679,13 @@ int run_pipeline(const RtScene* scene, const Wf2* w, const Wf2Space& sp, size_t 
                     hipLaunchKernelGGL((wf2_trace_kernel<ST, WF2_QUEUE>), tgrid[1], dim3(64), 0, stream, S, A, spg, *cam, rows, g, d_stats, status);
                     hipLaunchKernelGGL((wf2_prepare_kernel<ST, false>), wide, threads, 0, stream, S, A.pre, spg, *cam, rows, (int)depth, g, d_out, d_stats, status);
                 }
+                const bool more = g < depth && (S.flags & RT_SCENE_RECURSIVE);  // only hits with recursion budget left can have children
                 if (two) {
                     (void)hipEventRecord(w->prepared[g], stream);
                     (void)hipStreamWaitEvent(side, w->prepared[g], 0);
                 }
                 if (cands_pass) hipLaunchKernelGGL((wf2_cands_kernel<ST, WF2_SHADOW>), wide, threads, 0, side, S, spg, *cam, rows, g, d_stats, status);
                 hipLaunchKernelGGL((wf2_trace_kernel<ST, WF2_SHADOW>), tgrid[2], dim3(64), 0, side, S, A, spg, *cam, rows, g, d_stats, status);
-                const bool more = g < depth && (S.flags & RT_SCENE_RECURSIVE);  // only hits with recursion budget left can have children
                 if (more) {
                     hipLaunchKernelGGL((wf2_trace_kernel<ST, WF2_CONTAINERS>), tgrid[3], dim3(64), 0, stream, S, A, spg, *cam, rows, g, d_stats, status);
                     hipLaunchKernelGGL((wf2_spawn_kernel<ST>), wide, threads, 0, stream, S, spg, *cam, rows, g, stretch_shift, d_stats, status);
@@ -719,6 +719,11 @@ int run_pipeline(const RtScene* scene, const Wf2* w, const Wf2Space& sp, size_t 
         Wf2Counters c;
         HIP_TRY(hipStreamSynchronize(stream));
         HIP_TRY(hipMemcpy(&c, sp.cnt, sizeof c, hipMemcpyDeviceToHost));
+        std::fprintf(stderr, "wf2 counters: rays per generation");
+        for (unsigned g = 0; g <= depth; ++g) std::fprintf(stderr, " %u", c.n_rays[g]);
+        std::fprintf(stderr, " | hits whose children found no room");
+        for (unsigned g = 0; g <= depth; ++g) std::fprintf(stderr, " %u", c.n_overflow[g]);
+        std::fprintf(stderr, "\n");
         static const char* modes[4] = {"primary", "queue", "shadow", "containers"};
         for (int m = 0; m < 4; ++m) {
             const double tot = (double)(c.prof[m][0] + c.prof[m][1] + c.prof[m][2] + c.prof[m][3]);
