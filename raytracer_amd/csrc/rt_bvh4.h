@@ -18,12 +18,10 @@ static_assert(sizeof(Bvh4Node) == 64, "one node = four 16-byte words: half the w
 #define RT_BVH4_LEAF 0x80000000u
 #define RT_BVH4_DONE 0x7fffffffu
 #define RT_BVH4_NOPRE 0x40000000u  // in a leaf code: the leaf has no f32 pre-test (planes, triangles): its record is read for the ancestors only
-// ... and the class of its primitive's intersection code in bits 27-29 (0 sphere, 1 plane, 2 cube, 3 cylinder / cone,
-// 4 triangle): the traversal kernel picks the leaves a wave tests together by it
-#define RT_BVH4_CLASS_SHIFT 27
-#define RT_BVH4_CLASS(code) (((code) >> RT_BVH4_CLASS_SHIFT) & 7u)
-#define RT_BVH4_N_CLASSES 5
-#define RT_BVH4_SHAPE(code) ((code) & 0x07ffffffu)
+// bits 24-29 of a leaf code are zero in the hierarchy: the traversal kernel's leaf exchange puts the owner lane there (rt_wf2.h),
+// so the pipeline takes scenes of fewer than 2^24 shapes
+#define RT_BVH4_SHAPE_BITS 24
+#define RT_BVH4_SHAPE(code) ((code) & 0x00ffffffu)
 #ifndef RT_WF2_LDS_STACK
 #define RT_WF2_LDS_STACK 24   // stack entries per lane kept in LDS; deeper ones in private memory
 #endif
@@ -100,28 +98,21 @@ struct Walk {
     int sp;        // stack entries (entry 0 is the DONE sentinel)
 };
 
-// One step of the walk at an inner node: the four child boxes against the ray segment [0, t_far]; the nearest
-// child met becomes the node at hand, the others go on the stack.
+// The four child boxes of one node against the ray segment [t_near, t_far]: which of them the ray meets, and where it
+// enters them.  `org` / `expw` / `qlo` / `qhi`: the node's words as walk_step reads them per lane, or as a wave reads them
+// through scalar loads when all its lanes test the same node (wf2_packet_kernel).
 // (t_near = 0 for a ray; the containers walk also wants what lies behind the origin: a negative t_near, or -inf.)
-template <int LDS_N = RT_WF2_LDS_STACK, int STRIDE = 64, bool STATS, int FLAT>
-RT_DEV void walk_step(const Wf2Accel& A, const RayF32& f, float t_near, float t_far, Walk& w, uint32_t* lds_stack, uint32_t* deep,
-                      Ctx<STATS, FLAT>& cx) {
-    const uint4* __restrict__ q = reinterpret_cast<const uint4*>(A.nodes + w.cur);
-    const uint4 w0 = q[0], w1 = q[1], w2 = q[2];  // org + exponents | children | qlo[3], qhi[0]
-    const uint2 w3 = *reinterpret_cast<const uint2*>(q + 3);  // qhi[1], qhi[2]
-    count(cx, ST_ACCEL_F32, 4u);
-    const uint32_t kid[4] = {w1.x, w1.y, w1.z, w1.w};
-    const uint32_t qlo[3] = {w2.x, w2.y, w2.z}, qhi[3] = {w2.w, w3.x, w3.y};
+RT_DEV void node_children(const float org[3], uint32_t expw, const uint32_t kid[4], const uint32_t qlo[3], const uint32_t qhi[3],
+                          const RayF32& f, float t_near, float t_far, bool met[4], float tn_out[4]) {
     // plane(axis, child) = org + q * step, so t = q * (step * inv) + (org * inv + c): the slack in c (ray_f32) also covers
     // the one extra rounding of org * inv + c.  Which of an axis' two planes the ray meets first is the sign of its slope:
     // the four children's lo or hi bytes are picked as one word per axis, and entry / exit are a max3 / min3 of products --
     // no per-child min / max of the two planes; the twelve products per side go two to an instruction (v_pk_fma_f32).
     typedef float f2 __attribute__((ext_vector_type(2)));
-    const float org[3] = {__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z)};
     f2 n01[3], n23[3], f01[3], f23[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        const float step = __uint_as_float(((w0.w >> (8 * a)) & 0xffu) << 23);
+        const float step = __uint_as_float(((expw >> (8 * a)) & 0xffu) << 23);
         const float sinv = step * f.inv[a];
         const float cn = __builtin_fmaf(org[a], f.inv[a], f.cn[a]), cf = __builtin_fmaf(org[a], f.inv[a], f.cf[a]);
         const bool neg = f.inv[a] < 0.f;
@@ -132,9 +123,6 @@ RT_DEV void walk_step(const Wf2Accel& A, const RayF32& f, float t_near, float t_
         n01[a] = __builtin_elementwise_fma(bn01, s2, cn2), n23[a] = __builtin_elementwise_fma(bn23, s2, cn2);
         f01[a] = __builtin_elementwise_fma(bf01, s2, cf2), f23[a] = __builtin_elementwise_fma(bf23, s2, cf2);
     }
-    uint32_t next = RT_BVH4_DONE;
-    float t_next = __builtin_inff();
-    bool have = false;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const float nx = c < 2 ? n01[0][c & 1] : n23[0][c & 1], ny = c < 2 ? n01[1][c & 1] : n23[1][c & 1], nz = c < 2 ? n01[2][c & 1] : n23[2][c & 1];
@@ -142,8 +130,33 @@ RT_DEV void walk_step(const Wf2Accel& A, const RayF32& f, float t_near, float t_
         const float tn = fmaxf(fmaxf(nx, ny), nz);
         const float tf = fminf(fminf(fx, fy), fz);
         // (negated comparisons: a NaN anywhere lets the box through, as the f64 walk does)
-        const bool met = kid[c] != RT_BVH4_DONE && !(tn > tf) && !(tf < t_near) && !(tn > t_far);
-        if (met) {
+        met[c] = kid[c] != RT_BVH4_DONE && !(tn > tf) && !(tf < t_near) && !(tn > t_far);
+        tn_out[c] = tn;
+    }
+}
+
+// One step of the walk at an inner node: the four child boxes against the ray segment [t_near, t_far]; the nearest
+// child met becomes the node at hand, the others go on the stack.
+template <int LDS_N = RT_WF2_LDS_STACK, int STRIDE = 64, bool STATS, int FLAT>
+RT_DEV void walk_step(const Wf2Accel& A, const RayF32& f, float t_near, float t_far, Walk& w, uint32_t* lds_stack, uint32_t* deep,
+                      Ctx<STATS, FLAT>& cx) {
+    const uint4* __restrict__ q = reinterpret_cast<const uint4*>(A.nodes + w.cur);
+    const uint4 w0 = q[0], w1 = q[1], w2 = q[2];  // org + exponents | children | qlo[3], qhi[0]
+    const uint2 w3 = *reinterpret_cast<const uint2*>(q + 3);  // qhi[1], qhi[2]
+    count(cx, ST_ACCEL_F32, 4u);
+    const uint32_t kid[4] = {w1.x, w1.y, w1.z, w1.w};
+    const uint32_t qlo[3] = {w2.x, w2.y, w2.z}, qhi[3] = {w2.w, w3.x, w3.y};
+    const float org[3] = {__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z)};
+    bool met_c[4];
+    float tn_c[4];
+    node_children(org, w0.w, kid, qlo, qhi, f, t_near, t_far, met_c, tn_c);
+    uint32_t next = RT_BVH4_DONE;
+    float t_next = __builtin_inff();
+    bool have = false;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float tn = tn_c[c];
+        if (met_c[c]) {
             uint32_t other = kid[c];
             if (!have || tn < t_next) {
                 other = next;
@@ -174,10 +187,8 @@ RT_DEV void walk_pop(Walk& w, const uint32_t* lds_stack, const uint32_t* deep) {
 }
 
 // false: the ray's LINE certainly misses the leaf's primitive (see LeafPre).  `reach` = max |o| + extent of the ray.
-RT_DEV bool leaf_may_hit(const LeafPre* __restrict__ pre, const Ray& ray, float reach, uint32_t& anc0, uint32_t& anc1) {
-    const float4* __restrict__ q = reinterpret_cast<const float4*>(pre);
-    const float4 r0 = q[0], r1 = q[1], r2 = q[2], kk = q[3], cc = q[4];
-    anc0 = __float_as_uint(cc.z), anc1 = __float_as_uint(cc.w);
+// (r0, r1, r2 = the rows of the record's matrix, kk = k1, k2, kind, ymid, cc = yhalf, radius, anc[0], anc[1])
+RT_DEV bool leaf_may_hit_core(float4 r0, float4 r1, float4 r2, float4 kk, float4 cc, const Ray& ray, float reach) {
     const unsigned kind = __float_as_uint(kk.z);
     if (kind == RT_PRE_NONE) return true;
     const float ox = (float)ray.o.x, oy = (float)ray.o.y, oz = (float)ray.o.z;
@@ -219,6 +230,12 @@ RT_DEV bool leaf_may_hit(const LeafPre* __restrict__ pre, const Ray& ray, float 
         }
     }
     return true;
+}
+RT_DEV bool leaf_may_hit(const LeafPre* __restrict__ pre, const Ray& ray, float reach, uint32_t& anc0, uint32_t& anc1) {
+    const float4* __restrict__ q = reinterpret_cast<const float4*>(pre);
+    const float4 r0 = q[0], r1 = q[1], r2 = q[2], kk = q[3], cc = q[4];
+    anc0 = __float_as_uint(cc.z), anc1 = __float_as_uint(cc.w);
+    return leaf_may_hit_core(r0, r1, r2, kk, cc, ray, reach);
 }
 
 // The ray in the space of a leaf's parent: through the enclosing groups' transforms, outermost first (shape.rs:28-32 per
@@ -283,6 +300,70 @@ RT_DEV bool wf2_leaf(const SceneDev& S, int s, const Ray& world_ray, double limi
         Ray r = world_ray;
         if (!leaf_way_down<true>(S, parent, anc0, anc1, r, cx)) return false;
     }
+    if (SHADOW) return true;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if ((h.keep >> k) & 1u) offer(best, h.t[k], s);
+    return false;
+}
+
+// wf2_leaf for a leaf that the lanes of a wave test TOGETHER (wf2_packet_kernel): `s`, `anc0` and `anc1` are the same in every
+// lane, so the shape's record, its enclosing groups' records and their gates come through scalar loads (one per wave, the
+// values in scalar registers) instead of one vector read per lane and word; each lane brings its own ray.  Same operations
+// in the same order per lane as wf2_leaf (prim_intersect_rec is prim_intersect with the record handed in).  For leaves nested
+// at most two groups deep (anc0 != RT_PRE_DEEP).
+template <bool SHADOW, bool STATS, int FLAT>
+RT_DEV bool wf2_leaf_uniform(const SceneDev& S, int s, uint32_t anc0, uint32_t anc1, const Ray& world_ray, double limit, Best& best,
+                             Ctx<STATS, FLAT>& cx) {
+    const RtShape rec = load_uniform(S.g_shapes + s);
+    const unsigned kf = rec.kind_flags;
+    if (SHADOW && !(kf & RT_FLAG_HAS_SHADOW)) return false;
+    Ray at = world_ray;
+    if (anc0 != RT_PRE_NO_ANC) {
+        const RtShape g = load_uniform(S.g_shapes + anc0);
+        at = transform_ray(g.inv, at);
+        count(cx, ST_RAY_XFORM);
+    }
+    if (anc1 != RT_PRE_NO_ANC) {
+        const RtShape g = load_uniform(S.g_shapes + anc1);
+        at = transform_ray(g.inv, at);
+        count(cx, ST_RAY_XFORM);
+    }
+    const unsigned kind = RT_KIND(kf);
+    RtConic conic{0.0, 0.0};
+    if (kind == RT_CYLINDER || kind == RT_CONE) conic = load_uniform(S.g_conics + rec.param);
+    RtTriangle tri;
+    if (kind == RT_TRIANGLE || kind == RT_SMOOTH_TRIANGLE) tri = load_uniform(S.g_tris + rec.param);
+    PrimHits h;
+    prim_intersect_rec(rec.inv, kf, &conic, &tri, at, h, cx);
+    bool useful = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if ((h.keep >> k) & 1u) {
+            const double t = h.t[k];
+            if (SHADOW)
+                useful = useful || (t >= 0.0 && t < limit);
+            else
+                useful = useful || (t >= 0.0 && (t < best.t || (t == best.t && s > best.idx)));
+        }
+    }
+    // the way down again, this time past the gates (compound.rs:93-95), for the lanes that have a hit to offer
+    bool open = true;
+    if (useful) {
+        Ray r = world_ray;
+#pragma unroll
+        for (int level = 0; level < 2; ++level) {
+            const uint32_t anc = level == 0 ? anc0 : anc1;
+            if (anc == RT_PRE_NO_ANC) continue;
+            const RtShape g = load_uniform(S.g_shapes + anc);
+            r = transform_ray(g.inv, r);
+            if (RT_KIND(g.kind_flags) != RT_GROUP) continue;
+            const RtGroup gg = load_uniform(S.groups + g.param);
+            count(cx, ST_GATES);
+            open = open && gg.n_children != 0u && box_intersects(gg.bmin, gg.bmax, r);
+        }
+    }
+    if (!useful || !open) return false;
     if (SHADOW) return true;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -400,8 +481,25 @@ RT_DEV void containers_from_list(const SceneDev& S, LaneList& W, int n, double h
     }
 }
 
-// wf2_leaf for World::intersections as a sorted list cut at t <= bound (world_list): the primitive's surviving hits are
-// inserted with BTreeSet::append's tie rule.  Returns the new length.
+// wf2_leaf for World::intersections as a sorted list cut at t <= bound (world_list), the half that does not touch the list:
+// the primitive's collected hits in `h`, -> the mask of those the list takes (none when a gate on the way down is closed).
+template <bool STATS, int FLAT>
+RT_DEV unsigned wf2_leaf_hits(const SceneDev& S, int s, const Ray& world_ray, double bound, PrimHits& h, Ctx<STATS, FLAT>& cx,
+                              uint32_t anc0 = RT_PRE_DEEP, uint32_t anc1 = RT_PRE_NO_ANC) {
+    const RtShape* __restrict__ sh = S.shapes + s;
+    const unsigned kf = sh->kind_flags;
+    const int parent = anc0 == RT_PRE_DEEP ? sh->parent : -1;
+    Ray at = world_ray;
+    if (!leaf_way_down<true>(S, parent, anc0, anc1, at, cx)) return 0u;
+    prim_intersect(S, sh, kf, at, h, cx);
+    unsigned keep = 0u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (((h.keep >> k) & 1u) && h.t[k] <= bound) keep |= 1u << k;
+    return keep;
+}
+
+// ... and the whole: the primitive's surviving hits are inserted with BTreeSet::append's tie rule.  Returns the new length.
 template <bool STATS, int FLAT>
 // (keep_lo <= t < keep_hi: the range of the ray parameter whose entries this lane keeps, when a line is shared out among lanes)
 RT_DEV int wf2_leaf_list(const SceneDev& S, LaneList& W, int top, int s, const Ray& world_ray, double bound, Ctx<STATS, FLAT>& cx,

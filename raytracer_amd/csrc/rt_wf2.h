@@ -205,12 +205,16 @@ __global__ __launch_bounds__(256) void wf2_cands_kernel(const SceneDev S, Wf2Spa
     flush_stats(cx, stats, status);
 }
 
+// what a wave's lanes have written to LDS is there for the others to read
+RT_DEV void wf2_lds_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // The traversal kernel.  One-wave blocks; every lane holds at most one ray.
 #ifndef RT_WF2_CANDS_INLINE
 #define RT_WF2_CANDS_INLINE 1  // the traversal kernel evaluates the direction candidates when it takes a ray (a whole wave refills at once); 0: wf2_cands_kernel ahead of every trace launch, 21.8 ms against 21.4
-#endif
-#ifndef RT_WF2_SHADOW_HINT
-#define RT_WF2_SHADOW_HINT 0  // measured: 21.3 ms with, 21.0 without (most feelers of this scene reach their light; the extra test is paid by all)
 #endif
 #ifndef RT_WF2_MIN_CHUNK
 #define RT_WF2_MIN_CHUNK 8u
@@ -224,15 +228,24 @@ __global__ __launch_bounds__(256) void wf2_cands_kernel(const SceneDev S, Wf2Spa
 #ifndef RT_WF2_LIST_SPLIT
 #define RT_WF2_LIST_SPLIT 8u  // containers walks of small launches: lanes a line is shared out among at most (0: never)
 #endif
-#ifndef RT_WF2_LEAF_CLASSES
-#define RT_WF2_LEAF_CLASSES 0  // study knob (measured, slower): 1 = a round of leaf tests takes the leaves of ONE class of primitive, the wave's commonest; 2 = every lane takes one, of that class if it has one
-#endif
 #ifndef RT_WF2_LIST_SHARE
 #define RT_WF2_LIST_SHARE 1u
 #endif
 #ifndef RT_WF2_TRACE_WAVES
 #define RT_WF2_TRACE_WAVES 4  // waves per SIMD the traversal kernel is compiled for (<= 128 VGPRs)
 #endif
+#ifndef RT_WF2_SHARED_LEAVES
+// Feelers / containers walks: 1 = the wave's set-aside leaves dealt out to ALL its lanes (below: "leaf exchange"), 0 = every lane
+// tests its own, one a round.  Measured (profiles/r03_variants.txt): the exchange takes the lanes busy in a leaf round from
+// 0.56 to 0.72 (feelers) and from 0.27 to 0.63 (containers walks) -- and the leaf phases take as long as before, the frame
+// 17.64 ms against 17.23: a leaf round's cost is the vector memory transactions of its ACTIVE lanes (each leaf is ~25
+// scattered 16-byte reads), not the instructions a round issues.  Kept as a study knob.
+#define RT_WF2_SHARED_LEAVES 0
+#endif
+// Stack entries per lane in LDS by kind of walk (deeper ones in private memory): what is left of a wave's 10 KB share of the
+// CU's 160 KB (4 waves / SIMD) once the feelers' and containers walks' leaf exchange -- rays, work list, results -- has its room.
+#define RT_WF2_LDS_STACK_SHADOW 16
+#define RT_WF2_LDS_STACK_LIST 6
 template <bool STATS, int MODE>
 __global__ __launch_bounds__(64, RT_WF2_TRACE_WAVES) void wf2_trace_kernel(const SceneDev S, const Wf2Accel A, Wf2Space sp, RtCameraDesc cam, RowMap rows,
                                                        unsigned gen, RtStats* __restrict__ stats, unsigned* __restrict__ status) {
@@ -240,12 +253,24 @@ __global__ __launch_bounds__(64, RT_WF2_TRACE_WAVES) void wf2_trace_kernel(const
     constexpr bool SHADOW = MODE == WF2_SHADOW;
     constexpr bool LIST = MODE == WF2_CONTAINERS;  // n1 / n2 of the transparent hits: the sorted world list up to the hit
     constexpr int PEND = (SHADOW || LIST) ? RT_WF2_PEND : RT_WF2_PEND_COLOUR;  // leaves a lane may set aside while other lanes look for theirs
-    __shared__ uint32_t lds_stack_all[RT_WF2_LDS_STACK * 64];
-    __shared__ uint32_t pend_all[(PEND > 0 ? PEND : 1) * 64];
+    constexpr bool EXCHANGE = PEND > 0 && RT_WF2_SHARED_LEAVES != 0;           // ... and those leaves are dealt out to all lanes of the wave
+    constexpr int LDS_N = !EXCHANGE ? RT_WF2_LDS_STACK : (SHADOW ? RT_WF2_LDS_STACK_SHADOW : RT_WF2_LDS_STACK_LIST);
+    constexpr int RING = PEND > 0 ? PEND : 1;
+    __shared__ uint32_t lds_stack_all[LDS_N * 64];
+    __shared__ uint32_t pend_all[RING * 64];
+    // The leaf exchange (EXCHANGE): every ray of the wave's chunk in LDS -- a leaf is tested by whichever lane it is dealt to --,
+    // the work list (leaf code | owner lane << 24, so shapes < 2^24: wf2_create), and what comes back: a flag per ray
+    // (feelers) or the primitive's hits (containers walks).
+    __shared__ double x_ray[EXCHANGE ? 6 * 64 : 1];
+    __shared__ double x_lim[EXCHANGE ? 64 : 1];
+    __shared__ uint32_t x_work[EXCHANGE ? RING * 64 : 1];
+    __shared__ uint32_t x_hidden[EXCHANGE && SHADOW ? 64 : 1];
+    __shared__ double x_t[EXCHANGE && LIST ? 4 * 64 : 1];
+    __shared__ uint32_t x_sk[EXCHANGE && LIST ? 2 * 64 : 1];  // shape | keep mask
     uint32_t* lds_stack = lds_stack_all + threadIdx.x;
     uint32_t* pend = pend_all + threadIdx.x;
     unsigned p_head = 0, p_n = 0;
-    uint32_t deep[RT_WF2_MAX_STACK - RT_WF2_LDS_STACK];
+    uint32_t deep[RT_WF2_MAX_STACK - LDS_N];
     Ctx<STATS, CLS> cx;
     cx.status = 0;
     if constexpr (STATS) {
@@ -306,7 +331,7 @@ __global__ __launch_bounds__(64, RT_WF2_TRACE_WAVES) void wf2_trace_kernel(const
     bool dry = false;                        // the queue has no chunk left
     bool busy = false;
     unsigned item = 0;
-    Ray ray{v3(0.0, 0.0, 0.0), v3(0.0, 0.0, 1.0)};
+    Ray ray{v3(0.0, 0.0, 0.0), v3(0.0, 0.0, 1.0)};  // (EXCHANGE: only while a lane takes its ray; the leaf tests read x_ray)
     RayF32 f{};
     Best best{__builtin_inf(), -1};
     double limit = 0.0;
@@ -314,6 +339,41 @@ __global__ __launch_bounds__(64, RT_WF2_TRACE_WAVES) void wf2_trace_kernel(const
     float t_far = 0.f, t_near = 0.f;
     bool second_walk = false;  // LIST: the walk over the open primitives is still to come
     Walk w{RT_BVH4_DONE, 0};
+    auto push = [&](uint32_t code) {
+        if (w.sp < LDS_N)
+            lds_stack[w.sp * 64] = code;
+        else
+            deep[w.sp - LDS_N] = code;
+        ++w.sp;
+    };
+    // the ray and the limit (feelers: distance to the light; containers walks: where the list is cut) of the wave's lane `l`
+    auto ray_of = [&](unsigned l) {
+        if constexpr (EXCHANGE)
+            return Ray{v3(x_ray[0 * 64 + l], x_ray[1 * 64 + l], x_ray[2 * 64 + l]), v3(x_ray[3 * 64 + l], x_ray[4 * 64 + l], x_ray[5 * 64 + l])};
+        else
+            return ray;
+    };
+    auto limit_of = [&](unsigned l) {
+        if constexpr (EXCHANGE)
+            return x_lim[l];
+        else
+            return limit;
+    };
+    // a leaf ahead of its f64 test: the f32 test of the ray's line against the inflated primitive (LeafPre), and the enclosing
+    // groups' indices on the way
+    auto leaf_worth = [&](uint32_t leaf, const Ray& r, uint32_t& anc0, uint32_t& anc1) {
+        anc0 = RT_PRE_DEEP, anc1 = RT_PRE_NO_ANC;
+        if (!A.pre) return true;
+        const int s = (int)RT_BVH4_SHAPE(leaf);
+        if (leaf & RT_BVH4_NOPRE) {  // no pre-test for this kind: the record is read for the ancestors only
+            const uint2 anc = *reinterpret_cast<const uint2*>(&A.pre[s].anc[0]);
+            anc0 = anc.x, anc1 = anc.y;
+            return true;
+        }
+        const float reach = fmaxf(fmaxf(fabsf((float)r.o.x), fabsf((float)r.o.y)), fabsf((float)r.o.z)) * 1.000001f + A.extent_max;
+        count(cx, ST_ACCEL_F32);  // one more acceleration-only test
+        return leaf_may_hit(A.pre + s, r, reach, anc0, anc1);
+    };
 #ifdef RT_WF2_PROFILE
     unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, pn[2] = {0, 0};
 #define RT_STAMP(k) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); pt[k] += now_ - stamp_; stamp_ = now_; }
@@ -412,6 +472,12 @@ __global__ __launch_bounds__(64, RT_WF2_TRACE_WAVES) void wf2_trace_kernel(const
                     }
                     ray_f32(ray, A.extent, A.slack, f);
                     t_far = (SHADOW || LIST) ? f32_up(limit) : f32_up(best.t);
+                    if constexpr (EXCHANGE) {
+                        x_ray[0 * 64 + lane] = ray.o.x, x_ray[1 * 64 + lane] = ray.o.y, x_ray[2 * 64 + lane] = ray.o.z;
+                        x_ray[3 * 64 + lane] = ray.d.x, x_ray[4 * 64 + lane] = ray.d.y, x_ray[5 * 64 + lane] = ray.d.z;
+                        x_lim[lane] = limit;
+                        if constexpr (SHADOW) x_hidden[lane] = 0u;
+                    }
                     // LIST: the list is what the whole LINE meets up to the cut, behind the origin too (seg_near = -inf).
                     // (Study, RT_HIP_WF2_SEG_NEAR=1: a finite seg_near and a second walk over the open primitives only; see
                     // the header of this file for why that is not the default.)
@@ -429,8 +495,7 @@ __global__ __launch_bounds__(64, RT_WF2_TRACE_WAVES) void wf2_trace_kernel(const
                     if (valid && !found) {
                         w.cur = A.root;
                         for (unsigned k = 0; k < A.n_always; ++k) {
-                            lds_stack[w.sp * 64] = w.cur;
-                            ++w.sp;
+                            push(w.cur);
                             w.cur = RT_BVH4_LEAF | A.always[k];
                         }
                     }
@@ -449,9 +514,9 @@ __global__ __launch_bounds__(64, RT_WF2_TRACE_WAVES) void wf2_trace_kernel(const
         // ---- box tests only, until every busy lane holds a leaf or is through.  (Measured and rejected: leaving the loop
         // for the leaves at hand once only 4-48 lanes are still walking -- 30.7 ms at 0 and 4, 31.3-36.4 ms at 8-48.)
         // Feelers and the containers walk (PEND > 0): a lane that has its leaf does not idle while others still look for
-        // theirs -- it sets the leaf aside (a ring of PEND per lane in LDS, worked off one per round below, in the order
-        // found) and walks on.  Nothing a leaf yields could have shortened those walks much: a feeler that is lit goes
-        // through the whole segment anyway, the containers list is cut at a fixed bound.
+        // theirs -- it sets the leaf aside (a ring of PEND per lane in LDS) and walks on.  Nothing a leaf yields could have
+        // shortened those walks much: a feeler that is lit goes through the whole segment anyway, the containers list is
+        // cut at a fixed bound.
         if constexpr (PEND > 0) {
             for (;;) {
                 const bool inner = busy && w.cur < RT_BVH4_DONE;
@@ -461,11 +526,11 @@ __global__ __launch_bounds__(64, RT_WF2_TRACE_WAVES) void wf2_trace_kernel(const
                 pn[1] += 64u;
 #endif
                 if (inner) {
-                    walk_step(A, f, t_near, t_far, w, lds_stack, deep, cx);
+                    walk_step<LDS_N>(A, f, t_near, t_far, w, lds_stack, deep, cx);
                 } else if (busy && (w.cur & RT_BVH4_LEAF) && p_n < (unsigned)PEND) {
-                    pend[(RT_WF2_LEAF_CLASSES ? p_n : (p_head + p_n) % (unsigned)PEND) * 64u] = w.cur;
+                    pend[((p_head + p_n) % (unsigned)RING) * 64u] = w.cur;
                     ++p_n;
-                    walk_pop(w, lds_stack, deep);
+                    walk_pop<LDS_N>(w, lds_stack, deep);
                 }
             }
         } else {
@@ -473,109 +538,144 @@ __global__ __launch_bounds__(64, RT_WF2_TRACE_WAVES) void wf2_trace_kernel(const
             while (__builtin_amdgcn_ballot_w64(busy && w.cur < RT_BVH4_DONE) != 0ull) {
                 pn[0] += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(busy && w.cur < RT_BVH4_DONE));
                 pn[1] += 64u;
-                if (busy && w.cur < RT_BVH4_DONE) walk_step(A, f, t_near, t_far, w, lds_stack, deep, cx);
+                if (busy && w.cur < RT_BVH4_DONE) walk_step<LDS_N>(A, f, t_near, t_far, w, lds_stack, deep, cx);
             }
 #else
-            while (busy && w.cur < RT_BVH4_DONE) walk_step(A, f, t_near, t_far, w, lds_stack, deep, cx);
+            while (busy && w.cur < RT_BVH4_DONE) walk_step<LDS_N>(A, f, t_near, t_far, w, lds_stack, deep, cx);
 #endif
         }
         RT_STAMP(1)
-#ifdef RT_WF2_PROFILE
-        pt[4] += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(busy && (w.cur & RT_BVH4_LEAF)));
-        pt[5] += 64u;
-#endif
-        // ---- leaves: the oldest one set aside, else the one at hand.  Feelers (RT_WF2_SHADOW_HINT): a wave's feelers go to one
-        // light from neighbouring hits, so the primitive that has just hidden the light from one of them is tried by all the
-        // others at once, in a second pass of the same code -- any occluder will do (world.rs:85-96 asks only whether).
-        int hint = -1;
-#pragma nounroll
-        for (int pass = 0; pass < (SHADOW && RT_WF2_SHADOW_HINT ? 2 : 1); ++pass) {
-            bool take, keep_walk;
-            uint32_t leaf;
-            if (pass == 0 && PEND > 0 && RT_WF2_LEAF_CLASSES) {
-                // The leaves set aside are a bag, not a queue: of all the wave holds, this round tests those of ONE class of
-                // primitive -- the one most lanes have -- so that the intersection code below runs one branch with many
-                // lanes instead of five with a few each (the order in which a feeler or a containers walk meets its leaves
-                // changes nothing).  The leaf at hand joins the bag first when there is room.
-                if (busy && (w.cur & RT_BVH4_LEAF) && p_n < (unsigned)PEND) {
-                    pend[p_n * 64u] = w.cur;
+        // ---- leaves
+        bool own_leaves = true;  // every lane tests its own leaf, one a round (colour rays; LIST with a line shared among lanes)
+        if constexpr (EXCHANGE) {
+            if (split == 1u) {
+                // The wave's set-aside leaves dealt out to ALL its lanes.  Lines and feelers differ a lot in how many leaves
+                // they meet: worked off one per lane and round, a round ran with a quarter (containers walks) to a half
+                // (feelers) of the lanes, the others waiting for the lane with the most.  Here the leaves of all lanes go on
+                // one list and lane i tests item base + i, whose ever it is -- with that ray, read from LDS -- and hands the
+                // answer back through LDS: a flag (feelers: any occluder will do, world.rs:85-96) or the primitive's hits, which
+                // the owner then puts on its sorted list (the list's merge rule does not depend on the order of arrival:
+                // list_insert).  Nothing a test yields depends on which lane ran it.
+                own_leaves = false;
+                if (busy && (w.cur & RT_BVH4_LEAF) && p_n < (unsigned)PEND) {  // (the leaf at hand joins the others when there is room)
+                    pend[((p_head + p_n) % (unsigned)RING) * 64u] = w.cur;
                     ++p_n;
-                    walk_pop(w, lds_stack, deep);
+                    walk_pop<LDS_N>(w, lds_stack, deep);
                 }
-                unsigned mask = 0u;
+                const unsigned cnt = busy ? p_n : 0u;
+                unsigned off[RING];  // where this lane's k-th leaf goes: all lanes' first leaves, then their second ones, ...
+                unsigned total = 0u;
 #pragma unroll
-                for (unsigned k = 0; k < (unsigned)(PEND > 0 ? PEND : 1); ++k)
-                    if (busy && k < p_n) mask |= 1u << RT_BVH4_CLASS(pend[k * 64u]);
-                int cls = -1, most = 0;
-#pragma unroll
-                for (int c = 0; c < RT_BVH4_N_CLASSES; ++c) {
-                    const int n_c = __builtin_popcountll(__builtin_amdgcn_ballot_w64(((mask >> c) & 1u) != 0u));
-                    if (n_c > most) most = n_c, cls = c;
+                for (unsigned k = 0; k < (unsigned)RING; ++k) {
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64(cnt > k);
+                    off[k] = total + (unsigned)__builtin_popcountll(m & below);
+                    total += (unsigned)__builtin_popcountll(m);
                 }
-                take = RT_WF2_LEAF_CLASSES == 2 ? mask != 0u : (cls >= 0 && ((mask >> (cls >= 0 ? cls : 0)) & 1u) != 0u);
-                keep_walk = true;
-                leaf = RT_BVH4_DONE;
-                if (take) {
-                    unsigned at = 0u;  // (2: every lane takes a leaf, of the wave's commonest class if it has one)
+                if (total != 0u) {
 #pragma unroll
-                    for (unsigned k = (unsigned)(PEND > 0 ? PEND : 1); k-- > 0u;)
-                        if (k < p_n && RT_BVH4_CLASS(pend[k * 64u]) == (unsigned)cls) at = k;
-                    leaf = pend[at * 64u];
-                    --p_n;
-                    if (at != p_n) pend[at * 64u] = pend[p_n * 64u];
-                }
-            } else if (pass == 0) {
-                const bool from_ring = PEND > 0 && busy && p_n != 0u;
-                take = from_ring || (busy && (w.cur & RT_BVH4_LEAF));
-                keep_walk = from_ring;
-                leaf = w.cur;
-                if constexpr (PEND > 0) {
-                    if (from_ring) {
-                        leaf = pend[p_head * 64u];
-                        p_head = (p_head + 1u) % (unsigned)PEND;
-                        --p_n;
+                    for (unsigned k = 0; k < (unsigned)RING; ++k)
+                        if (k < cnt) x_work[off[k]] = (pend[((p_head + k) % (unsigned)RING) * 64u] & 0xc0ffffffu) | (lane << 24);
+                    p_head = p_n = 0u;
+                    wf2_lds_wave_sync();
+                    for (unsigned base = 0u; base < total; base += 64u) {
+                        const unsigned idx = base + lane;
+                        bool take = idx < total;
+                        const uint32_t it = take ? x_work[idx] : 0u;
+                        const unsigned owner = (it >> 24) & 63u;
+                        const uint32_t leaf = it & 0xc0ffffffu;
+                        if constexpr (SHADOW) take = take && x_hidden[owner] == 0u;  // (that ray already has its occluder)
+#ifdef RT_WF2_PROFILE
+                        pt[4] += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(take));
+                        pt[5] += 64u;
+#endif
+                        const int s = (int)RT_BVH4_SHAPE(leaf);
+                        bool hit = false;
+                        unsigned keep = 0u;
+                        PrimHits h;
+                        h.t[0] = h.t[1] = h.t[2] = h.t[3] = 0.0;
+                        if (take) {
+                            const Ray r = ray_of(owner);
+                            const double lim = limit_of(owner);
+                            uint32_t anc0, anc1;
+                            if (leaf_worth(leaf, r, anc0, anc1)) {
+                                if constexpr (LIST) {
+                                    keep = wf2_leaf_hits(S, s, r, lim, h, cx, anc0, anc1);
+                                } else {
+                                    Best none{__builtin_inf(), -1};
+                                    hit = wf2_leaf<true>(S, s, r, lim, none, cx, anc0, anc1);
+                                }
+                            }
+                        }
+                        if constexpr (SHADOW) {
+                            if (hit) x_hidden[owner] = 1u;
+                        } else {
+                            x_sk[lane] = (uint32_t)s, x_sk[64 + lane] = keep;
+                            x_t[0 * 64 + lane] = h.t[0], x_t[1 * 64 + lane] = h.t[1], x_t[2 * 64 + lane] = h.t[2], x_t[3 * 64 + lane] = h.t[3];
+                        }
+                        wf2_lds_wave_sync();
+                        if constexpr (LIST) {  // the owners take what came back for them in this batch
+#pragma unroll
+                            for (unsigned k = 0; k < (unsigned)RING; ++k) {
+                                const unsigned j = off[k] - base;  // (wraps for an item of an earlier batch)
+                                if (k < cnt && j < 64u) {
+                                    const unsigned kept = x_sk[64 + j];
+                                    const uint32_t shape = x_sk[j];
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q)
+                                        if ((kept >> q) & 1u) {
+                                            top = list_insert(W, 0, top, x_t[q * 64 + j], shape, cx.status);
+                                            count(cx, ST_LIST_ENTRIES);
+                                        }
+                                }
+                            }
+                        }
+                        wf2_lds_wave_sync();  // (the next batch writes the same words)
+                    }
+                    if constexpr (SHADOW) {
+                        if (busy && x_hidden[lane] != 0u) {
+                            found = true;
+                            w.cur = RT_BVH4_DONE;
+                        }
                     }
                 }
-            } else {
-                if (hint < 0) break;  // (the same in every lane)
-                take = busy && !found;
-                keep_walk = true;
-                leaf = RT_BVH4_LEAF | (uint32_t)hint;  // (pre-tested again: the hint carries no flag)
             }
-            const int s = (int)RT_BVH4_SHAPE(leaf);
-            bool hit_shadow = false;
-            if (take) {
-                bool worth = true;
-                uint32_t anc0 = RT_PRE_DEEP, anc1 = RT_PRE_NO_ANC;
-                if (A.pre) {
-                    if (leaf & RT_BVH4_NOPRE) {  // no pre-test for this kind: the record is read for the ancestors only
-                        const uint2 anc = *reinterpret_cast<const uint2*>(&A.pre[s].anc[0]);
-                        anc0 = anc.x, anc1 = anc.y;
-                    } else {
-                        const float reach = fmaxf(fmaxf(fabsf((float)ray.o.x), fabsf((float)ray.o.y)), fabsf((float)ray.o.z)) * 1.000001f + A.extent_max;
-                        worth = leaf_may_hit(A.pre + s, ray, reach, anc0, anc1);
-                        count(cx, ST_ACCEL_F32);  // one more acceleration-only test
-                    }
+        }
+        if (own_leaves) {
+            // the oldest leaf set aside, else the one at hand
+            const bool from_ring = PEND > 0 && busy && p_n != 0u;
+            const bool take = from_ring || (busy && (w.cur & RT_BVH4_LEAF));
+            uint32_t leaf = w.cur;
+            if constexpr (PEND > 0) {
+                if (from_ring) {
+                    leaf = pend[p_head * 64u];
+                    p_head = (p_head + 1u) % (unsigned)RING;
+                    --p_n;
                 }
-                if (worth) {
+            }
+#ifdef RT_WF2_PROFILE
+            pt[4] += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(take));
+            pt[5] += 64u;
+#endif
+            if (take) {
+                const int s = (int)RT_BVH4_SHAPE(leaf);
+                const Ray r = ray_of(lane);
+                const double lim = limit_of(lane);
+                bool hit_shadow = false;
+                uint32_t anc0, anc1;
+                if (leaf_worth(leaf, r, anc0, anc1)) {
                     if constexpr (LIST)
-                        top = wf2_leaf_list(S, W, top, s, ray, limit, cx, anc0, anc1, keep_lo, keep_hi);
+                        top = wf2_leaf_list(S, W, top, s, r, lim, cx, anc0, anc1, keep_lo, keep_hi);
                     else
-                        hit_shadow = wf2_leaf<SHADOW>(S, s, ray, limit, best, cx, anc0, anc1);
+                        hit_shadow = wf2_leaf<SHADOW>(S, s, r, lim, best, cx, anc0, anc1);
                 }
                 if (SHADOW && hit_shadow) {
                     found = true;
                     w.cur = RT_BVH4_DONE;
                     p_n = 0u;
-                } else if (!keep_walk) {
+                } else if (!from_ring) {
                     if (!LIST && !SHADOW) t_far = f32_up(best.t);
-                    walk_pop(w, lds_stack, deep);
+                    walk_pop<LDS_N>(w, lds_stack, deep);
                 }
-            }
-            if (SHADOW && RT_WF2_SHADOW_HINT && pass == 0) {
-                const unsigned long long hitters = __builtin_amdgcn_ballot_w64(take && hit_shadow);
-                if (hitters != 0ull && __builtin_amdgcn_ballot_w64(busy && !found) != 0ull)
-                    hint = __shfl(s, __builtin_ctzll(hitters), 64);
             }
         }
         RT_STAMP(2)
@@ -655,6 +755,243 @@ __global__ __launch_bounds__(64, RT_WF2_TRACE_WAVES) void wf2_trace_kernel(const
                 sp.hits[item] = h;
             }
             busy = false;
+        }
+        RT_STAMP(3)
+    }
+#ifdef RT_WF2_PROFILE
+    if (lane == 0) {
+        for (int k = 0; k < 4; ++k) atomicAdd(&sp.cnt->prof[MODE][k], pt[k]);
+        atomicAdd(&sp.cnt->prof[MODE][4], pn[0]);
+        atomicAdd(&sp.cnt->prof[MODE][5], pn[1]);
+        atomicAdd(&sp.cnt->prof[MODE][6], pt[4]);
+        atomicAdd(&sp.cnt->prof[MODE][7], pt[5]);
+    }
+#endif
+    flush_stats(cx, stats, status);
+}
+
+// The traversal kernel for COHERENT launches: camera rays (a wave = an 8 x 8 tile of pixels) and the feelers of the first
+// generation (numbered light-major from neighbouring hits: a wave's feelers go to one light from one patch of the scene).
+// Such rays meet the same nodes and mostly the same leaves, and wf2_trace_kernel -- every lane its own walk -- spends its
+// time on vector memory transactions: 4 scattered 16-byte reads per lane and node, ~25 per lane and leaf (TA busy 0.66-0.72,
+// VALU busy 0.2; the leaf exchange above showed that it is the reads of the ACTIVE lanes that cost, not the instructions).
+// Here the WAVE walks: one stack for all 64 rays (LDS: node code + the lanes that met its box), one node at a time read
+// through scalar loads (64 bytes, once per wave, into scalar registers), its four child boxes tested by every lane that is
+// still in it with its own ray, ballots say which children any lane met, and they go on the stack nearest first (by the
+// first such lane's distances).  A leaf is tested by the lanes that met its box, together, its records again through
+// scalar loads (wf2_leaf_uniform).  Every lane thus tests exactly the leaves whose chain of boxes its own ray meets within
+// its own current reach -- what the per-lane walk guarantees --, so the closest hit / the occlusion answer is the same
+// (neither depends on the order of the tests).
+#ifndef RT_WF2_PACKET
+#define RT_WF2_PACKET 1  // 0: wf2_trace_kernel for every launch (studies)
+#endif
+template <bool STATS, int MODE>
+__global__ __launch_bounds__(64, RT_WF2_TRACE_WAVES) void wf2_packet_kernel(const SceneDev S, const Wf2Accel A, Wf2Space sp, RtCameraDesc cam, RowMap rows,
+                                                        unsigned gen, RtStats* __restrict__ stats, unsigned* __restrict__ status) {
+    static_assert(MODE == WF2_PRIMARY || MODE == WF2_SHADOW, "closest hits of camera rays, or feelers");
+    constexpr int CLS = RT_CLASS_NESTED_LEAVES;
+    constexpr bool SHADOW = MODE == WF2_SHADOW;
+    // the wave's stack: a walk pushes at most three entries per level it descends (wf2_create bounds the per-lane walk's
+    // need by RT_WF2_MAX_STACK in the same way), the unbounded leaves and the root
+    __shared__ uint32_t pk_code[RT_WF2_MAX_STACK + 12];
+    __shared__ unsigned long long pk_mask[RT_WF2_MAX_STACK + 12];
+    Ctx<STATS, CLS> cx;
+    cx.status = 0;
+    if constexpr (STATS) {
+#pragma unroll
+        for (int i = 0; i < ST_COUNT; ++i) cx.cnt[i] = 0;
+    }
+    const PixelMap pm = pixel_map(cam, rows);
+    const unsigned n_hits = SHADOW ? wf2_n_slots(sp, gen, pm) : 0u;
+    const unsigned n = SHADOW ? n_hits * S.n_lights : pm.n_items;
+    Wf2Padded* chunk_counters = sp.cnt->chunk[3u * gen + (SHADOW ? 1u : 0u)];
+    unsigned chunk = A.chunk > 64u ? 64u : A.chunk;  // (one ray per lane)
+    {
+        const unsigned long long slots = gridDim.x;  // fewer rays than 64 for every resident wave: one even chunk each (see wf2_trace_kernel)
+        if (slots * chunk > n) {
+            const unsigned even = (unsigned)((n + slots - 1u) / slots);
+            chunk = even < RT_WF2_MIN_CHUNK ? RT_WF2_MIN_CHUNK : (even < chunk ? even : chunk);
+        }
+    }
+    const unsigned per_part = ((n + chunk - 1u) / chunk + RT_WF2_PARTS - 1u) / RT_WF2_PARTS * chunk;
+    unsigned part = blockIdx.x % RT_WF2_PARTS, parts_left = RT_WF2_PARTS;
+    unsigned part_lo = part * per_part;
+    unsigned part_hi = part_lo + per_part < n ? part_lo + per_part : n;
+    if (part_lo > n) part_lo = part_hi = n;
+    const unsigned lane = threadIdx.x;
+#ifdef RT_WF2_PROFILE
+    unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, pn[2] = {0, 0};
+    unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
+#endif
+    for (;;) {
+        // ---- the wave's next chunk of rays
+        unsigned c = 0xffffffffu;
+        for (;;) {
+            if (part_lo < part_hi) {
+                if (lane == 0) c = atomicAdd(&chunk_counters[part].v, chunk);
+                c = (unsigned)__builtin_amdgcn_readfirstlane((int)c);
+                if (c < part_hi - part_lo) break;
+            }
+            c = 0xffffffffu;
+            if (--parts_left == 0u) break;
+            part = (part + 1u) % RT_WF2_PARTS;
+            part_lo = part * per_part;
+            part_hi = part_lo + per_part < n ? part_lo + per_part : n;
+            if (part_lo > n) part_lo = part_hi = n;
+        }
+        if (c == 0xffffffffu) break;  // (the same in every lane)
+        const unsigned first = part_lo + c;
+        const unsigned avail = first + chunk < part_hi ? chunk : part_hi - first;
+        const unsigned item = first + lane;
+        Ray ray{v3(0.0, 0.0, 0.0), v3(0.0, 0.0, 1.0)};
+        double limit = 0.0;
+        Best best{__builtin_inf(), -1};
+        bool found = false;
+        bool valid = lane < avail && wf2_item_ray<MODE>(S, sp, cam, rows, pm, item, n_hits, ray, limit);
+        if (valid && (MODE == WF2_PRIMARY || SHADOW)) count(cx, SHADOW ? ST_RAY_SHADOW : ST_RAY_PRIMARY);
+        // the direction index's candidates first, every lane its own (primitive.rs:486-490's branch: see RtDirCand)
+        if (A.has_cands && valid) found = wf2_candidates<SHADOW>(S, ray, limit, best, cx);
+        RayF32 f;
+        ray_f32(ray, A.extent, A.slack, f);
+        float t_far = SHADOW ? f32_up(limit) : f32_up(best.t);
+        bool alive = valid && !found;  // the lane still has a question (feelers: no occluder yet)
+        RT_STAMP(0)
+        // ---- the wave's walk.  (LDS traffic between the lanes of ONE wave needs no fence: a wave's LDS instructions are
+        // carried out in the order issued; the wave barriers below only keep the compiler from moving them.)
+        // (Keeping the nearest child in registers instead of pushing and popping it was measured: 0.8 ms slower.)
+        unsigned sp_top = 0u;  // entries on the wave's stack (the same in every lane)
+        {
+            const unsigned long long all = __builtin_amdgcn_ballot_w64(alive);
+            if (all != 0ull) {
+                if (lane == 0) {
+                    pk_code[0] = A.root, pk_mask[0] = all;
+                    for (unsigned k = 0; k < A.n_always; ++k) pk_code[1u + k] = RT_BVH4_LEAF | A.always[k], pk_mask[1u + k] = all;
+                }
+                sp_top = 1u + A.n_always;  // (the unbounded leaves on top: tested first, a plane's hit bounds the walk)
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        for (;;) {
+            if (sp_top == 0u) break;
+            --sp_top;
+            const uint32_t code = (uint32_t)__builtin_amdgcn_readfirstlane((int)pk_code[sp_top]);
+            const unsigned long long m = pk_mask[sp_top];
+            const unsigned long long mask = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(m >> 32)) << 32) |
+                                            (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m);
+            const bool act = alive && ((mask >> lane) & 1ull) != 0ull;
+            const unsigned long long amask = __builtin_amdgcn_ballot_w64(act);
+            if (amask == 0ull || code == RT_BVH4_DONE) continue;
+            if (code & RT_BVH4_LEAF) {
+                RT_STAMP(1)
+#ifdef RT_WF2_PROFILE
+                pt[4] += (unsigned)__builtin_popcountll(amask);
+                pt[5] += 64u;
+#endif
+                const int s = (int)RT_BVH4_SHAPE(code);
+                uint32_t anc0 = RT_PRE_DEEP, anc1 = RT_PRE_NO_ANC;
+                bool worth = act;
+                if (A.pre) {
+                    const LeafPre pre = load_uniform(A.pre + s);
+                    anc0 = pre.anc[0], anc1 = pre.anc[1];
+                    if (!(code & RT_BVH4_NOPRE) && act) {
+                        const float reach = fmaxf(fmaxf(fabsf((float)ray.o.x), fabsf((float)ray.o.y)), fabsf((float)ray.o.z)) * 1.000001f + A.extent_max;
+                        const float4 r0 = {pre.m[0], pre.m[1], pre.m[2], pre.m[3]}, r1 = {pre.m[4], pre.m[5], pre.m[6], pre.m[7]};
+                        const float4 r2 = {pre.m[8], pre.m[9], pre.m[10], pre.m[11]};
+                        const float4 kk = {pre.k1, pre.k2, __uint_as_float(pre.kind), pre.ymid};
+                        const float4 cc = {pre.yhalf, pre.radius, 0.f, 0.f};
+                        worth = leaf_may_hit_core(r0, r1, r2, kk, cc, ray, reach);
+                        count(cx, ST_ACCEL_F32);
+                    }
+                }
+                if (__builtin_amdgcn_ballot_w64(worth) == 0ull) {
+                    RT_STAMP(2)
+                    continue;
+                }
+                bool hit = false;
+                if (anc0 == RT_PRE_DEEP) {  // nested deeper than the record says: every lane the long way round
+                    if (worth) hit = wf2_leaf<SHADOW>(S, s, ray, limit, best, cx);
+                } else if (worth) {
+                    hit = wf2_leaf_uniform<SHADOW>(S, s, anc0, anc1, ray, limit, best, cx);
+                }
+                if constexpr (SHADOW) {
+                    if (hit) found = true, alive = false;
+                } else {
+                    t_far = f32_up(best.t);
+                }
+                RT_STAMP(2)
+                continue;
+            }
+#ifdef RT_WF2_PROFILE
+            pn[0] += (unsigned)__builtin_popcountll(amask);
+            pn[1] += 64u;
+#endif
+            // an inner node: its 64 bytes once per wave
+            const Bvh4Node nd = load_uniform(A.nodes + code);
+            bool met[4] = {false, false, false, false};
+            float tn[4] = {0.f, 0.f, 0.f, 0.f};
+            const uint32_t kid[4] = {(uint32_t)nd.child[0], (uint32_t)nd.child[1], (uint32_t)nd.child[2], (uint32_t)nd.child[3]};
+            if (act) {
+                const uint32_t expw = (uint32_t)nd.exp[0] | ((uint32_t)nd.exp[1] << 8) | ((uint32_t)nd.exp[2] << 16);
+                uint32_t qlo[3], qhi[3];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    qlo[a] = (uint32_t)nd.qlo[a][0] | ((uint32_t)nd.qlo[a][1] << 8) | ((uint32_t)nd.qlo[a][2] << 16) | ((uint32_t)nd.qlo[a][3] << 24);
+                    qhi[a] = (uint32_t)nd.qhi[a][0] | ((uint32_t)nd.qhi[a][1] << 8) | ((uint32_t)nd.qhi[a][2] << 16) | ((uint32_t)nd.qhi[a][3] << 24);
+                }
+                node_children(nd.org, expw, kid, qlo, qhi, f, 0.f, t_far, met, tn);
+                count(cx, ST_ACCEL_F32, 4u);
+            }
+            // which children any lane met, and where the first lane of the node meets them (children it does not meet: at
+            // infinity, so they come first in the order below)
+            unsigned long long cm[4];
+            uint32_t key[4];  // (distances are >= 0: their bit patterns order as the numbers do)
+            uint32_t kc[4] = {kid[0], kid[1], kid[2], kid[3]};
+            const int rep = __builtin_ctzll(amask);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                cm[k] = __builtin_amdgcn_ballot_w64(act && met[k]);
+                key[k] = (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(met[k] ? tn[k] : __builtin_inff()), rep);
+            }
+            // the four in descending order of that distance (a network of five exchanges on wave-uniform values): the far
+            // ones go on the stack in that order, the nearest becomes the node at hand; children nobody met are skipped
+            auto exchange = [&](int i, int j) {
+                if (key[i] < key[j]) {
+                    const uint32_t t = key[i];
+                    key[i] = key[j], key[j] = t;
+                    const unsigned long long m = cm[i];
+                    cm[i] = cm[j], cm[j] = m;
+                    const uint32_t c2 = kc[i];
+                    kc[i] = kc[j], kc[j] = c2;
+                }
+            };
+            exchange(0, 1), exchange(2, 3), exchange(0, 2), exchange(1, 3), exchange(1, 2);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (cm[q] != 0ull) {
+                    if (lane == 0) pk_code[sp_top] = kc[q], pk_mask[sp_top] = cm[q];
+                    ++sp_top;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        RT_STAMP(1)
+        // ---- the answers
+        if (valid) {
+            if constexpr (SHADOW) {
+                sp.occ[item] = found ? 1 : 0;
+            } else {
+                Wf2Hit h;
+                h.t = best.t, h.idx = best.idx, h.pad = 0;
+                sp.hits[item] = h;
+            }
+        } else if (lane < avail) {  // an item without a ray (a tile's slot outside the frame, a hit-less context): as wf2_trace_kernel leaves it
+            if constexpr (SHADOW) {
+                sp.occ[item] = 0;
+            } else {
+                Wf2Hit h;
+                h.t = __builtin_inf(), h.idx = -1, h.pad = 0;
+                sp.hits[item] = h;
+            }
         }
         RT_STAMP(3)
     }
@@ -868,11 +1205,6 @@ RT_DEV bool may_have_children(const RtMaterial& m, uint32_t remaining) {
 // 8-byte words of the calling wave's own, record strides of 17 and 9 words so that the lanes' field stores spread over the
 // banks -- and leave in whole 512-byte rows.
 #define RT_WF2_STAGE_WORDS 1152u  // max(64 nodes x 17, 128 items x 9) 8-byte words
-RT_DEV void wf2_lds_wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 RT_DEV bool wf2_commit(const WfSpace& ws, unsigned shard, unsigned level, bool want, uint32_t parent, V3 surface,
                        double reflective, double transparency, const Children& ch, V3 reflect_o, V3 reflect_d,
                        int remaining_children, uint32_t& node_out, uint2* stage) {

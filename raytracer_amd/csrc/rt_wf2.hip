@@ -27,6 +27,8 @@ struct Wf2 {
     void* blocks[16] = {};
     size_t batch_pixels = 0, q_items = 0, node_items = 0;
     int trace_blocks_per_cu[2][4] = {};  // [stats][mode], from the occupancy query
+    int packet_blocks_per_cu[2][2] = {};  // wf2_packet_kernel: [stats][camera rays, feelers]
+    unsigned packet = 0;                  // which launches the wave-walk kernel takes: 1 camera rays, 2 the first generation's feelers
     int n_cus = 0;
     int side_blocks = 0;  // feelers on the second stream: one-wave blocks per CU (0: as many as fit)
     // a generation's containers walks run beside its feelers (neither reads what the other writes): a stream of the
@@ -431,7 +433,7 @@ int rth::wf2_create(const RtSceneDesc& d, uint32_t scene_flags, Arena& arena, Wf
     // What the pipeline covers: a world-level hierarchy whose leaves are primitives (nested in groups or not), no CSG
     // node and no shadowless primitive anywhere (those need the sorted world list per ray: the older kernels have it).
     if (d.world_bvh_root < 0 || (scene_flags & RT_SCENE_HAS_SHADOWLESS) || d.n_csgs != 0 || d.n_lights == 0) return RT_OK;
-    if (d.n_shapes >= (1u << RT_BVH4_CLASS_SHIFT)) return RT_OK;  // (a leaf code keeps its top five bits for flags and the class)
+    if (d.n_shapes >= (1u << RT_BVH4_SHAPE_BITS)) return RT_OK;  // (a leaf code's upper bits: flags, and the owner lane in the leaf exchange)
     std::vector<TNode> tree;
     std::vector<uint32_t> top;
     if (!parse_seq(d, d.world_bvh_root, -1, tree, top, 0) || top.empty()) return RT_OK;
@@ -526,9 +528,6 @@ int rth::wf2_create(const RtSceneDesc& d, uint32_t scene_flags, Arena& arena, Wf
             if ((code & RT_BVH4_LEAF) && code != RT_BVH4_DONE) {
                 const uint32_t shape = RT_BVH4_SHAPE(code);
                 if (pre[shape].kind == RT_PRE_NONE) code |= RT_BVH4_NOPRE;
-                const unsigned kind = RT_KIND(d.shapes[shape].kind_flags);
-                const uint32_t cls = kind == RT_SPHERE ? 0u : (kind == RT_PLANE ? 1u : (kind == RT_CUBE ? 2u : (kind == RT_CYLINDER || kind == RT_CONE ? 3u : 4u)));
-                code |= cls << RT_BVH4_CLASS_SHIFT;
             }
             return code;
         };
@@ -564,6 +563,7 @@ int rth::wf2_create(const RtSceneDesc& d, uint32_t scene_flags, Arena& arena, Wf
             bool known = false;
             int n_cus = 0;
             int blocks[2][4] = {};
+            int packet[2][2] = {};
         };
         static PerDevice known[64];
         int dev = 0;
@@ -575,10 +575,15 @@ int rth::wf2_create(const RtSceneDesc& d, uint32_t scene_flags, Arena& arena, Wf
             HIP_TRY(hipDeviceGetAttribute(&pd.n_cus, hipDeviceAttributeMultiprocessorCount, dev));
             int rc = RT_OK;
 #define RT_OCC(ST, MODE) if (rc == RT_OK) rc = occupancy(wf2_trace_kernel<ST, MODE>, &pd.blocks[ST ? 1 : 0][MODE]);
+            // (what the kernels' LDS use is sized for: 16 one-wave blocks per compute unit -- rt_wf2.h, RT_WF2_LDS_STACK_*)
             RT_OCC(false, WF2_PRIMARY) RT_OCC(false, WF2_QUEUE) RT_OCC(false, WF2_SHADOW)
             RT_OCC(true, WF2_PRIMARY) RT_OCC(true, WF2_QUEUE) RT_OCC(true, WF2_SHADOW)
             RT_OCC(false, WF2_CONTAINERS) RT_OCC(true, WF2_CONTAINERS)
 #undef RT_OCC
+            if (rc == RT_OK) rc = occupancy(wf2_packet_kernel<false, WF2_PRIMARY>, &pd.packet[0][0]);
+            if (rc == RT_OK) rc = occupancy(wf2_packet_kernel<false, WF2_SHADOW>, &pd.packet[0][1]);
+            if (rc == RT_OK) rc = occupancy(wf2_packet_kernel<true, WF2_PRIMARY>, &pd.packet[1][0]);
+            if (rc == RT_OK) rc = occupancy(wf2_packet_kernel<true, WF2_SHADOW>, &pd.packet[1][1]);
             if (rc != RT_OK) return rc;
             pd.known = true;
         }
@@ -586,6 +591,10 @@ int rth::wf2_create(const RtSceneDesc& d, uint32_t scene_flags, Arena& arena, Wf
         if (const char* e = std::getenv("RT_HIP_WF2_SIDE_BLOCKS")) w->side_blocks = std::atoi(e);
         else w->side_blocks = RT_WF2_SIDE_BLOCKS;
         std::memcpy(w->trace_blocks_per_cu, pd.blocks, sizeof pd.blocks);
+        std::memcpy(w->packet_blocks_per_cu, pd.packet, sizeof pd.packet);
+        // RT_HIP_WF2_PACKET (studies): bit 0 = camera rays, bit 1 = the first generation's feelers walked by the wave together
+        w->packet = RT_WF2_PACKET ? 3u : 0u;
+        if (const char* e = std::getenv("RT_HIP_WF2_PACKET")) w->packet = (unsigned)std::atoi(e) & 3u;
         const char* side_env = std::getenv("RT_HIP_WF2_SIDE");
         if (!(side_env && *side_env == '0')) {
             HIP_TRY(hipStreamCreateWithFlags(&w->side, hipStreamNonBlocking));
@@ -672,7 +681,10 @@ int run_pipeline(const RtScene* scene, const Wf2* w, const Wf2Space& sp, size_t 
                 if (two && g >= 2u) (void)hipStreamWaitEvent(stream, w->lit[g - 2u], 0);  // this set's last readers are through
                 if (g == 0) {
                     if (cands_pass) hipLaunchKernelGGL((wf2_cands_kernel<ST, WF2_PRIMARY>), wide, threads, 0, stream, S, spg, *cam, rows, g, d_stats, status);
-                    hipLaunchKernelGGL((wf2_trace_kernel<ST, WF2_PRIMARY>), tgrid[0], dim3(64), 0, stream, S, A, spg, *cam, rows, g, d_stats, status);
+                    if (w->packet & 1u)
+                        hipLaunchKernelGGL((wf2_packet_kernel<ST, WF2_PRIMARY>), dim3((unsigned)(w->n_cus * w->packet_blocks_per_cu[ST][0])), dim3(64), 0, stream, S, A, spg, *cam, rows, g, d_stats, status);
+                    else
+                        hipLaunchKernelGGL((wf2_trace_kernel<ST, WF2_PRIMARY>), tgrid[0], dim3(64), 0, stream, S, A, spg, *cam, rows, g, d_stats, status);
                     hipLaunchKernelGGL((wf2_prepare_kernel<ST, true>), wide, threads, 0, stream, S, A.pre, spg, *cam, rows, (int)depth, g, d_out, d_stats, status);
                 } else {
                     if (cands_pass) hipLaunchKernelGGL((wf2_cands_kernel<ST, WF2_QUEUE>), wide, threads, 0, stream, S, spg, *cam, rows, g, d_stats, status);
@@ -685,7 +697,10 @@ int run_pipeline(const RtScene* scene, const Wf2* w, const Wf2Space& sp, size_t 
                     (void)hipStreamWaitEvent(side, w->prepared[g], 0);
                 }
                 if (cands_pass) hipLaunchKernelGGL((wf2_cands_kernel<ST, WF2_SHADOW>), wide, threads, 0, side, S, spg, *cam, rows, g, d_stats, status);
-                hipLaunchKernelGGL((wf2_trace_kernel<ST, WF2_SHADOW>), tgrid[2], dim3(64), 0, side, S, A, spg, *cam, rows, g, d_stats, status);
+                if (g == 0u && (w->packet & 2u))
+                    hipLaunchKernelGGL((wf2_packet_kernel<ST, WF2_SHADOW>), dim3((unsigned)(w->n_cus * w->packet_blocks_per_cu[ST][1])), dim3(64), 0, side, S, A, spg, *cam, rows, g, d_stats, status);
+                else
+                    hipLaunchKernelGGL((wf2_trace_kernel<ST, WF2_SHADOW>), tgrid[2], dim3(64), 0, side, S, A, spg, *cam, rows, g, d_stats, status);
                 if (more) {
                     hipLaunchKernelGGL((wf2_trace_kernel<ST, WF2_CONTAINERS>), tgrid[3], dim3(64), 0, stream, S, A, spg, *cam, rows, g, d_stats, status);
                     hipLaunchKernelGGL((wf2_spawn_kernel<ST>), wide, threads, 0, stream, S, spg, *cam, rows, g, stretch_shift, d_stats, status);

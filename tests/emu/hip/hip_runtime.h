@@ -117,6 +117,7 @@ inline void block_barrier() { if (block) (void)block->exchange(threadIdx.x, 0ull
 }  // namespace hip_emu
 #define __builtin_amdgcn_ballot_w64(x) hip_emu::ballot(x)
 #define __builtin_amdgcn_readfirstlane(x) hip_emu::first_lane(x)
+#define __builtin_amdgcn_readlane(x, l) hip_emu::shfl((x), (l))
 #define __builtin_amdgcn_wave_barrier() hip_emu::wave_barrier()
 #define __builtin_amdgcn_fence(...) ((void)0)
 #define __builtin_amdgcn_s_memtime() 0ull

@@ -14,7 +14,7 @@ import csv, sys, re
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # the last frame: from the last PRIMARY trace launch of the non-counting variant on
-starts = [i for i, r in enumerate(rows) if "wf2_trace_kernel<false, 0>" in r["Kernel_Name"]]
+starts = [i for i, r in enumerate(rows) if "wf2_trace_kernel<false, 0>" in r["Kernel_Name"] or "wf2_packet_kernel<false, 0>" in r["Kernel_Name"]]
 first = starts[-1] if starts else 0
 t0 = int(rows[first]["Start_Timestamp"])
 def short(n):

@@ -12,13 +12,19 @@ def best(fn, n=3):
         t = time.perf_counter(); out = fn(); ts.append(time.perf_counter() - t)
     return min(ts), out
 
-for name in ("pattern", "glass_bubble"):
-    world, cam = rt.exercise(name, 4096, 2160)
+# the exercises at 4K, then the bench's own scene (10 000 primitives: the tables are 10 MB, the flatten and the device
+# hierarchy build are no longer small) at 4K and at 8K
+cases = [("pattern", 4096, 2160), ("glass_bubble", 4096, 2160), ("synthetic", 4096, 2160), ("synthetic", 7680, 4320)]
+if len(sys.argv) > 1:
+    cases = [c for c in cases if c[0] in sys.argv[1:]]
+for name, W, H in cases:
+    world, cam = rt.synthetic(W, H, 10000) if name == "synthetic" else rt.exercise(name, W, H)
+    MB = W * H * 3 * 8 / 1e6
     cam.render(world)  # warm-up
     _, (img, st) = best(lambda: cam.render(world, stats=True), 1)  # the counting kernel: rays per frame
     rays = st.rays_primary + st.rays_shadow + st.rays_reflect + st.rays_refract
     t, _ = best(lambda: cam.render(world))
-    print(f"{name} 4096x2160 via rt_hip_render (flatten + scene upload + kernel + 212 MB f64 frame to the caller's pageable buffer): "
+    print(f"{name} {W}x{H} via rt_hip_render (flatten + scene upload + kernel + {MB:.0f} MB f64 frame to the caller's pageable buffer): "
           f"{t*1e3:.1f} ms wall, {rays/t/1e6:.0f} Mrays/s PCIe-inclusive")
     # the C ABI call alone: tables already flattened, the caller's buffer already touched (as a Canvas's Vec is)
     import ctypes as C
@@ -47,8 +53,17 @@ for name in ("pattern", "glass_bubble"):
     print(f"  rt_hip_scene_render on the resident scene: {tr*1e3:.2f} ms f64, {tr8*1e3:.2f} ms rgb8")
     scene.close()
     t8, rgb8 = best(lambda: cam.render_rgb8(world))
-    print(f"{name} 4096x2160 via rt_hip_render_rgb8 (the same, quantised on the device: 26.5 MB): {t8*1e3:.1f} ms wall, "
+    print(f"{name} {W}x{H} via rt_hip_render_rgb8 (the same, quantised on the device: {MB/8:.1f} MB): {t8*1e3:.1f} ms wall, "
           f"{rays/t8/1e6:.0f} Mrays/s PCIe-inclusive")
+    if name == "synthetic":  # where the time of a first call goes
+        tfl, _ = best(lambda: world.flatten(), 3)
+        def create():
+            sc = rt.DeviceScene(flat); sc.close()
+        tcr, _ = best(create, 3)
+        print(f"  of which: flatten on the host {tfl*1e3:.1f} ms; rt_hip_scene_create + destroy (upload, device tables, hierarchy) {tcr*1e3:.1f} ms; "
+              f"kernels {tr8*1e3:.2f} ms; f64 frame to the host {max(tr - tr8, 0)*1e3:.2f} ms more than the rgb8 one")
+    if W > 4096:
+        continue  # (the text writer below is measured at 4K)
     tq, q = best(lambda: img.quantized(), 1)
     assert np.array_equal(q, rgb8)
     tf, text = best(lambda: rt.Canvas.ppm_from_rgb8(rgb8))
