@@ -28,7 +28,9 @@ std::mutex g_block_mutex;
 std::vector<Block> g_free_blocks;  // oldest first
 std::vector<Block> g_live_blocks;
 size_t g_cached_bytes = 0;
-constexpr size_t kMaxCachedBytes = (size_t)1 << 30;  // per process; past that the oldest idle blocks go back to the driver
+// per process; past that the oldest idle blocks go back to the driver.  Sized for the device: twice the kernel pipeline's
+// largest workspace (rt_wf2.hip, RT_WF2_BUDGET_MB = 24 GiB of the 288) -- a block of more than half the limit is never kept.
+constexpr size_t kMaxCachedBytes = (size_t)48 << 30;
 constexpr size_t kMaxCachedBlocks = 16;
 
 void evict_locked(size_t keep_bytes, size_t keep_blocks) {

@@ -1295,8 +1295,8 @@ RT_DEV bool wf2_commit(const WfSpace& ws, unsigned shard, unsigned level, bool w
 // long as its slowest wave, come and go.
 template <bool STATS>
 __global__ __launch_bounds__(256, RT_WF2_FINISH_WAVES) void wf2_spawn_kernel(const SceneDev S, Wf2Space sp, RtCameraDesc cam, RowMap rows, unsigned gen,
-                                                                            unsigned stretch_shift, RtStats* __restrict__ stats,
-                                                                            unsigned* __restrict__ status) {
+                                                                            unsigned stretch_shift, unsigned inlane_below,
+                                                                            RtStats* __restrict__ stats, unsigned* __restrict__ status) {
     constexpr int CLS = RT_CLASS_NESTED_LEAVES;
     Ctx<STATS, CLS> cx;
     cx.status = 0;
@@ -1309,6 +1309,10 @@ __global__ __launch_bounds__(256, RT_WF2_FINISH_WAVES) void wf2_spawn_kernel(con
     const PixelMap pm = pixel_map(cam, rows);
     const unsigned n = wf2_n_slots(sp, gen, pm);
     const unsigned n_round = (n + 63u) & ~63u;
+    // A generation that has thinned out below what the device holds at once (a launch that began with more): its hits keep
+    // their subtrees in their lanes (wf2_overflow_kernel, as for children that find no room) -- the generations that would
+    // follow are launches as long as their slowest wave with most of the device idle.  See RT_WF2_INLANE_BELOW.
+    const bool inlane = pm.n_items >= inlane_below && n < inlane_below;
     for (unsigned slot = blockIdx.x * blockDim.x + threadIdx.x; slot < n_round; slot += gridDim.x * blockDim.x) {
         const uint32_t mat = slot < n ? ctx_u(sp, slot, CU_MAT) : 0xffffffffu;
         Shade sd;
@@ -1335,7 +1339,7 @@ __global__ __launch_bounds__(256, RT_WF2_FINISH_WAVES) void wf2_spawn_kernel(con
         // a wave's children go to the shard picked by where they come from: a stretch of consecutive hits
         const unsigned out_shard = (((unsigned)__builtin_amdgcn_readfirstlane((int)slot) >> stretch_shift) * 2654435761u) >> 24;
         uint32_t node;
-        const bool placed = wf2_commit(sp.ws, out_shard, gen, want, parent, v3(0.0, 0.0, 0.0), reflective, transparency, ch, sd.over,
+        const bool placed = wf2_commit(sp.ws, out_shard, gen, want && !inlane, parent, v3(0.0, 0.0, 0.0), reflective, transparency, ch, sd.over,
                                       sd.reflect_v, (int)remaining - 1, node, stage);
         if (placed) {
             if (ch.do_reflect) count(cx, ST_RAY_REFLECT);
@@ -1486,28 +1490,76 @@ RT_DEV unsigned wf2_sort_key(const WfItem& it, float ex, float ey, float ez) {
     }
     return key;
 }
-__global__ __launch_bounds__(256) void wf2_compact_kernel(Wf2Space sp, unsigned gen, float ex, float ey, float ez) {
+// (Round 3: 1024 threads per slice instead of 256 -- one block per compute unit wants every wave slot it can get --, each
+// item's key kept in LDS between the counting pass and the moving pass, the 512 counters scanned by one wave instead of one
+// lane, and an item moved by four lanes, 16 bytes each, so that a wave's loads and stores cover whole 64-byte items.)
+#ifndef RT_WF2_COMPACT_THREADS
+#ifdef RT_HOST_EMU
+#define RT_WF2_COMPACT_THREADS 256u
+#else
+#define RT_WF2_COMPACT_THREADS 1024u
+#endif
+#endif
+#define RT_WF2_COMPACT_KEYS 24576u  // items of a slice whose keys are remembered (the others work theirs out again)
+__global__ __launch_bounds__(RT_WF2_COMPACT_THREADS) void wf2_compact_kernel(Wf2Space sp, unsigned gen, float ex, float ey, float ez) {
     constexpr unsigned KEYS = RT_WF_BINS * RT_WF2_SORT_CELLS * RT_WF2_SORT_CELLS * RT_WF2_SORT_CELLS;
-    __shared__ unsigned count[KEYS], start[KEYS];
+    constexpr unsigned PER = (KEYS + 63u) / 64u;  // counters per lane of the scanning wave
+    static_assert(KEYS <= 65536u, "keys are kept as 16-bit values");
+    static_assert(sizeof(WfItem) == 64, "an item is moved as four 16-byte pieces");
+    __shared__ unsigned count[KEYS];
+    __shared__ unsigned short keys[RT_WF2_COMPACT_KEYS];
+    const unsigned nt = blockDim.x, tid = threadIdx.x;
     const unsigned shard = blockIdx.x;
     const unsigned begin = sp.cnt->offsets[shard], n = sp.cnt->offsets[shard + 1u] - begin;
     const WfItem* __restrict__ src = sp.ws.queue[(gen + 1u) & 1u] + (size_t)shard * sp.ws.q_cap;
     WfItem* __restrict__ dst = sp.qd + begin;
-    for (unsigned k = threadIdx.x; k < KEYS; k += 256u) count[k] = 0u;
+    for (unsigned k = tid; k < KEYS; k += nt) count[k] = 0u;
     __syncthreads();
-    for (unsigned i = threadIdx.x; i < n; i += 256u) atomicAdd(&count[wf2_sort_key(src[i], ex, ey, ez)], 1u);
+    for (unsigned i = tid; i < n; i += nt) {
+        const unsigned key = wf2_sort_key(src[i], ex, ey, ez);
+        if (i < RT_WF2_COMPACT_KEYS) keys[i] = (unsigned short)key;
+        atomicAdd(&count[key], 1u);
+    }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned run = 0;
-        for (unsigned o = 0; o < KEYS; ++o) {
-            start[o] = run;
-            run += count[o];
+    if (tid < 64u) {  // counts -> where each key's run starts
+        unsigned mine[PER], sum = 0u;
+#pragma unroll
+        for (unsigned j = 0; j < PER; ++j) {
+            const unsigned k = tid * PER + j;
+            mine[j] = k < KEYS ? count[k] : 0u;
+            sum += mine[j];
+        }
+        unsigned incl = sum;
+#pragma unroll
+        for (unsigned off = 1u; off < 64u; off <<= 1) {
+            const unsigned up = __shfl_up(incl, off, 64);
+            if (tid >= off) incl += up;
+        }
+        unsigned run = incl - sum;
+#pragma unroll
+        for (unsigned j = 0; j < PER; ++j) {
+            const unsigned k = tid * PER + j;
+            if (k < KEYS) count[k] = run;
+            run += mine[j];
         }
     }
     __syncthreads();
-    for (unsigned i = threadIdx.x; i < n; i += 256u) {
-        const WfItem it = src[i];
-        dst[atomicAdd(&start[wf2_sort_key(it, ex, ey, ez)], 1u)] = it;
+    const uint4* __restrict__ src4 = reinterpret_cast<const uint4*>(src);
+    uint4* __restrict__ dst4 = reinterpret_cast<uint4*>(dst);
+    const unsigned piece = tid & 3u;
+    const unsigned n_round = (n + 15u) & ~15u;  // (whole waves reach the shuffle below)
+    for (unsigned i = tid >> 2; i < n_round; i += nt >> 2) {
+        unsigned to = 0u;
+        uint4 v = {0u, 0u, 0u, 0u};
+        if (i < n) {
+            v = src4[(size_t)i * 4u + piece];
+            if (piece == 0u) {
+                const unsigned key = i < RT_WF2_COMPACT_KEYS ? (unsigned)keys[i] : wf2_sort_key(src[i], ex, ey, ez);
+                to = atomicAdd(&count[key], 1u);
+            }
+        }
+        to = (unsigned)__shfl((int)to, (int)((tid & 63u) & ~3u), 64);
+        if (i < n) dst4[(size_t)to * 4u + piece] = v;
     }
 }
 

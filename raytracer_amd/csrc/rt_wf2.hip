@@ -29,6 +29,7 @@ struct Wf2 {
     int trace_blocks_per_cu[2][4] = {};  // [stats][mode], from the occupancy query
     int packet_blocks_per_cu[2][2] = {};  // wf2_packet_kernel: [stats][camera rays, feelers]
     unsigned packet = 0;                  // which launches the wave-walk kernel takes: 1 camera rays, 2 the first generation's feelers
+    unsigned inlane_below = 0;            // wf2_spawn_kernel: generations with fewer hits keep their subtrees in-lane (0: never)
     int n_cus = 0;
     int side_blocks = 0;  // feelers on the second stream: one-wave blocks per CU (0: as many as fit)
     // a generation's containers walks run beside its feelers (neither reads what the other writes): a stream of the
@@ -297,6 +298,14 @@ int occupancy(K kernel, int* out) {
 #define RT_WF2_BUDGET_MB 24576
 #endif
 
+// Generations with fewer hits than this finish in-lane (wf2_spawn_kernel); RT_HIP_WF2_INLANE_BELOW in the environment: studies.
+// Measured on rank 0's share of the 4K frame of the 10k scene (tools/gpu_shard_time.py), threshold 0 / 131072 / 262144 / 524288:
+// 1/4 share 6.17 / 6.16 / 6.14 / 10.77 ms, 1/8 share 4.11 / 4.12 / 7.30 / 10.26 ms -- wherever it triggers it loses: a lane that
+// keeps a subtree runs color_at's frame stack at 256 VGPRs, two waves per SIMD, its rays one after the other.  Off.
+#ifndef RT_WF2_INLANE_BELOW
+#define RT_WF2_INLANE_BELOW 0u
+#endif
+
 size_t budget_bytes() {
     static const size_t v = [] {
         const char* e = std::getenv("RT_HIP_WF_BUDGET_MB");
@@ -334,13 +343,13 @@ Plan plan_for(size_t items, size_t q_items, size_t node_items, uint32_t n_lights
 }
 
 // The workspace of a plan laid out in one block of device memory (256-byte aligned pieces); false when it does not fit.
-bool carve_space(Wf2Space& s, unsigned char* base, size_t bytes, const Plan& p, uint32_t n_lights) {
+bool carve_space(Wf2Space& s, unsigned char* base, size_t bytes, const Plan& p, uint32_t n_lights, size_t* used = nullptr) {
     size_t at = 0;
     bool ok = true;
     auto take = [&](auto** ptr, size_t n) {
         at = (at + 255u) & ~(size_t)255u;
         if (at + n > bytes) ok = false;
-        *ptr = reinterpret_cast<std::remove_reference_t<decltype(**ptr)>*>(base + at);
+        *ptr = base ? reinterpret_cast<std::remove_reference_t<decltype(**ptr)>*>(base + at) : nullptr;  // (no base: measuring)
         at += n;
     };
     std::memset(&s, 0, sizeof s);
@@ -363,18 +372,22 @@ bool carve_space(Wf2Space& s, unsigned char* base, size_t bytes, const Plan& p, 
     s.ws.q_cap = (unsigned)p.q_cap, s.ws.node_cap = (unsigned)p.node_cap;
     s.qd_cap = (unsigned)p.qd_cap, s.ctx_cap = (unsigned)p.ctx_cap;
     s.creq_part_cap = wf2_creq_part_cap(p.ctx_cap);
+    if (used) *used = at;
     return ok;
 }
 
 void free_space(Wf2* w) {
     for (void*& p : w->blocks) {
-        if (p) (void)hipFree(p);
+        if (p) rth::block_free(p);
         p = nullptr;
     }
     std::memset(&w->sp, 0, sizeof w->sp);
     w->batch_pixels = 0;
 }
 
+// One block from the library's cache of device blocks (rt_hostmem.hip), laid out by carve_space: a scene created, rendered
+// once and destroyed -- what rt_hip_render does per call -- takes the workspace the scene before it gave back instead of
+// fifteen hipMalloc / hipFree pairs (the 8K frame's 17 GB: 450 of the call's 530 ms).
 int ensure_space(Wf2* w, size_t items, size_t q_items, size_t node_items, uint32_t n_lights) {
     if (w->sp.cnt && w->batch_pixels >= items && w->q_items == q_items && w->node_items == node_items) return RT_OK;
     if (w->sp.cnt) {
@@ -383,45 +396,20 @@ int ensure_space(Wf2* w, size_t items, size_t q_items, size_t node_items, uint32
     }
     const Plan p = plan_for(items, q_items, node_items, n_lights);
     if (p.node_cap * RT_WF_SHARDS >= 0x40000000ull || p.qd_cap >= 0x80000000ull || p.ctx_cap >= 0x80000000ull) return RT_ERR_INVALID_ARG;
-    int nb = 0;
-    int rc = RT_OK;
-    auto get = [&](auto** ptr, size_t bytes) {
-        if (rc != RT_OK) return;
-        void* q = nullptr;
-        const hipError_t e = hipMalloc(&q, bytes ? bytes : 16);
-        if (e != hipSuccess) {
-            rc = rth::hip_fail(e, "hipMalloc(kernel pipeline workspace)");
-            return;
-        }
-        w->blocks[nb++] = q;
-        *ptr = reinterpret_cast<std::remove_reference_t<decltype(**ptr)>*>(q);
-    };
-    Wf2Space& s = w->sp;
-    get(&s.ws.queue[0], p.qd_cap * sizeof(WfItem));
-    s.ws.queue[1] = s.ws.queue[0];  // the sliced queue is emptied (compacted) before the next generation fills it
-    get(&s.ws.nodes, p.node_cap * RT_WF_SHARDS * sizeof(WfNode));
-    get(&s.ws.shards, RT_WF_SHARDS * sizeof(WfShard));
-    get(&s.qd, p.qd_cap * sizeof(WfItem));
-    get(&s.hits, p.ctx_cap * sizeof(Wf2Hit));
-    get(&s.ctx_d, p.ctx_cap * CX_DOUBLES * sizeof(double));
-    get(&s.ctx_u, p.ctx_cap * CU_UINTS * sizeof(uint32_t));
-    get(&s.occ, p.ctx_cap * (n_lights ? n_lights : 1u));
-    get(&s.creq, (size_t)RT_WF2_PARTS * wf2_creq_part_cap(p.ctx_cap) * sizeof(uint32_t));
-    get(&s.overflow, p.ctx_cap * sizeof(uint32_t));
-    get(&s.alt_ctx_d, p.ctx_cap * CX_DOUBLES * sizeof(double));
-    get(&s.alt_ctx_u, p.ctx_cap * CU_UINTS * sizeof(uint32_t));
-    get(&s.alt_occ, p.ctx_cap * (n_lights ? n_lights : 1u));
-    get(&s.alt_overflow, p.ctx_cap * sizeof(uint32_t));
-    get(&s.cnt, sizeof(Wf2Counters));
-    if (rc != RT_OK) {
-        (void)hipGetLastError();
-        free_space(w);
-        return rc;
+    size_t bytes = 0;
+    {
+        Wf2Space measure;
+        (void)carve_space(measure, nullptr, ~(size_t)0, p, n_lights, &bytes);  // (what the layout comes to, alignment included)
     }
-    s.ws.cam = nullptr;
-    s.ws.q_cap = (unsigned)p.q_cap, s.ws.node_cap = (unsigned)p.node_cap;
-    s.qd_cap = (unsigned)p.qd_cap, s.ctx_cap = (unsigned)p.ctx_cap;
-    s.creq_part_cap = wf2_creq_part_cap(p.ctx_cap);
+    void* block = nullptr;
+    const int rc = rth::block_alloc(&block, bytes);
+    if (rc != RT_OK) return rc;
+    w->blocks[0] = block;
+    if (!carve_space(w->sp, static_cast<unsigned char*>(block), bytes, p, n_lights)) {
+        free_space(w);
+        return RT_ERR_INVALID_ARG;  // (cannot happen: plan_for sized the block)
+    }
+    w->sp.ws.cam = nullptr;
     w->batch_pixels = items, w->q_items = q_items, w->node_items = node_items;
     return RT_OK;
 }
@@ -595,6 +583,8 @@ int rth::wf2_create(const RtSceneDesc& d, uint32_t scene_flags, Arena& arena, Wf
         // RT_HIP_WF2_PACKET (studies): bit 0 = camera rays, bit 1 = the first generation's feelers walked by the wave together
         w->packet = RT_WF2_PACKET ? 3u : 0u;
         if (const char* e = std::getenv("RT_HIP_WF2_PACKET")) w->packet = (unsigned)std::atoi(e) & 3u;
+        w->inlane_below = RT_WF2_INLANE_BELOW;
+        if (const char* e = std::getenv("RT_HIP_WF2_INLANE_BELOW")) w->inlane_below = (unsigned)std::atol(e);
         const char* side_env = std::getenv("RT_HIP_WF2_SIDE");
         if (!(side_env && *side_env == '0')) {
             HIP_TRY(hipStreamCreateWithFlags(&w->side, hipStreamNonBlocking));
@@ -703,7 +693,7 @@ int run_pipeline(const RtScene* scene, const Wf2* w, const Wf2Space& sp, size_t 
                     hipLaunchKernelGGL((wf2_trace_kernel<ST, WF2_SHADOW>), tgrid[2], dim3(64), 0, side, S, A, spg, *cam, rows, g, d_stats, status);
                 if (more) {
                     hipLaunchKernelGGL((wf2_trace_kernel<ST, WF2_CONTAINERS>), tgrid[3], dim3(64), 0, stream, S, A, spg, *cam, rows, g, d_stats, status);
-                    hipLaunchKernelGGL((wf2_spawn_kernel<ST>), wide, threads, 0, stream, S, spg, *cam, rows, g, stretch_shift, d_stats, status);
+                    hipLaunchKernelGGL((wf2_spawn_kernel<ST>), wide, threads, 0, stream, S, spg, *cam, rows, g, stretch_shift, w->inlane_below, d_stats, status);
                     if (two) {
                         (void)hipEventRecord(w->spawned[g], stream);
                         (void)hipStreamWaitEvent(side, w->spawned[g], 0);
@@ -714,7 +704,7 @@ int run_pipeline(const RtScene* scene, const Wf2* w, const Wf2Space& sp, size_t 
                 if (two) (void)hipEventRecord(w->lit[g], side);
                 if (!more) break;
                 hipLaunchKernelGGL(wf2_scan_kernel, dim3(1), dim3(RT_WF_SHARDS), 0, stream, spg, g);
-                hipLaunchKernelGGL(wf2_compact_kernel, dim3(RT_WF_SHARDS), threads, 0, stream, spg, g, A.extent[0], A.extent[1], A.extent[2]);
+                hipLaunchKernelGGL(wf2_compact_kernel, dim3(RT_WF_SHARDS), dim3(RT_WF2_COMPACT_THREADS), 0, stream, spg, g, A.extent[0], A.extent[1], A.extent[2]);
             }
             if (two) {  // every colour is where the folding below (and the next batch, and the caller) expects it
                 (void)hipStreamWaitEvent(stream, w->lit[last], 0);

@@ -9,6 +9,7 @@
 #include <thread>
 #include <cstring>
 #include <map>
+#include <unordered_map>
 #include <string>
 
 namespace rt {
@@ -311,7 +312,7 @@ struct Flattener {
     bool global = false;             // one world-space hierarchy over all leaves instead of one per group level
     std::vector<BvhItem> leaves;     // global: every primitive outside CSG nodes and every outermost CSG node
     std::vector<const Primitive*> prim_of;            // by shape index, nullptr for compounds
-    std::map<std::string, uint32_t> material_cache;   // identical materials share one record
+    std::unordered_map<std::string, uint32_t> material_cache;  // identical materials share one record
 
     static void key_append(std::string& k, const void* p, size_t n) { k.append(static_cast<const char*>(p), n); }
     static void pattern_key(std::string& k, const Pattern& p) {
@@ -373,9 +374,9 @@ struct Flattener {
         return false;
     }
 
-    // Appends the subtree of `s`; returns its acceleration box in the parent's space.
+    // Appends the subtree of `s`.
     // `to_world` maps the space of `s`'s parent to world space (only used for the global hierarchy).
-    ABox emit(const Shape& s, int32_t parent, uint32_t depth, const Matrix4& to_world = Matrix4::identity()) {
+    void emit(const Shape& s, int32_t parent, uint32_t depth, const Matrix4& to_world = Matrix4::identity()) {
         const uint32_t idx = static_cast<uint32_t>(out.shapes.size());
         if (global && csg_depth == 0 && (s.is_primitive() || s.compound().kind() == Compound::Kind::Csg))
             leaves.push_back(BvhItem{tight_box(s, to_world), idx});
@@ -419,7 +420,7 @@ struct Flattener {
             }
             rec.skip = idx + 1;
             out.shapes[idx] = rec;
-            return primitive_box(p, Matrix4::identity());
+            return;
         }
 
         const Compound& c = s.compound();
@@ -441,9 +442,10 @@ struct Flattener {
             // twelve wedges the ball is cut with)
             const bool tree = opt.build_bvh && !global && (csg_depth == 0 || !holds_conic(s));
             std::vector<BvhItem> items;
+            const Matrix4 below = global ? to_world * c.properties().transform : to_world;
             for (const Shape& child : c.children()) {
                 const uint32_t child_idx = static_cast<uint32_t>(out.shapes.size());
-                emit(child, static_cast<int32_t>(idx), depth + 1, global ? to_world * c.properties().transform : to_world);
+                emit(child, static_cast<int32_t>(idx), depth + 1, below);
                 if (tree) items.push_back(BvhItem{tight_box(child, Matrix4::identity()), child_idx});
             }
             if (tree && wants_bvh(c.children().size(), c.children()))
@@ -469,7 +471,6 @@ struct Flattener {
         }
         rec.skip = static_cast<uint32_t>(out.shapes.size());
         out.shapes[idx] = rec;
-        return ABox();  // callers take tight_box() of the subtree instead
     }
 };
 
@@ -668,6 +669,9 @@ FlatScene flatten(const World& world, const FlattenOptions& opt) {
     // which is built over the global form (the teapot 1.63 -> 1.31 ms).
     f.global = opt.build_bvh && (opt.hierarchy == 2 || (opt.hierarchy == 0 && nested_groups && n_leaves >= opt.bvh_min_children &&
                                                          (n_leaves < 64 * n_groups || (n_leaves >= 2048 && !has_csg))));
+    f.out.shapes.reserve(n_leaves + n_groups), f.prim_of.reserve(n_leaves + n_groups), f.out.groups.reserve(n_groups);
+    f.material_cache.reserve(n_leaves);
+    if (f.global) f.leaves.reserve(n_leaves);
     const bool timing = std::getenv("RT_FLATTEN_TIMING") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };

@@ -22,8 +22,9 @@ for line in out.splitlines():
         rows.append(cur)
     elif cur is not None:
         cur[key] = val
-print(f"{'kernel':70s} {'VGPR':>5s} {'AGPR':>5s} {'spill':>6s} {'scratch':>8s} {'LDS':>7s} {'occ':>4s} {'SGPR':>5s}")
+print(f"{'kernel':70s} {'VGPR':>5s} {'AGPR':>5s} {'vspill':>6s} {'sspill':>6s} {'scratch':>8s} {'LDS':>7s} {'occ':>4s} {'SGPR':>5s}")
 for r in rows:
     name = subprocess.run(["c++filt", "-p", r["name"]], capture_output=True, text=True).stdout.strip() or r["name"]
     get = lambda k: next((v for kk, v in r.items() if kk.startswith(k)), "?")
-    print(f"{name[:70]:70s} {get('VGPRs'):>5s} {get('AGPRs'):>5s} {get('VGPR Spill'):>6s} {get('ScratchSize'):>8s} {get('LDS Size'):>7s} {get('Occupancy'):>4s} {get('SGPRs'):>5s}")
+    print(f"{name[:70]:70s} {get('VGPRs:') if False else r.get('VGPRs', '?'):>5s} {r.get('AGPRs', '?'):>5s} {get('VGPRs Spill'):>6s} {get('SGPRs Spill'):>6s} "
+          f"{get('ScratchSize'):>8s} {get('LDS Size'):>7s} {get('Occupancy'):>4s} {get('TotalSGPRs'):>5s}")
