@@ -157,8 +157,8 @@ uint32_t pick_resolution(uint32_t n_cands, uint32_t hint) {
 }  // namespace
 
 void rth::dir_index_free(DirIndex* ix) {
-    if (ix->d_cell_start) (void)hipFree(ix->d_cell_start);
-    if (ix->d_entries) (void)hipFree(ix->d_entries);
+    if (ix->d_cell_start) rth::block_free(ix->d_cell_start);
+    if (ix->d_entries) rth::block_free(ix->d_entries);
     ix->d_cell_start = ix->d_entries = nullptr;
     ix->res = ix->n_entries = 0;
 }
@@ -175,42 +175,42 @@ int rth::dir_index_build(const RtDirCand* d_cands, uint32_t n_cands, uint32_t re
     auto fail = [&](hipError_t e, const char* what) { rc = rth::hip_fail(e, what); };
     for (;;) {
         const size_t n_cells = (size_t)6 * res * res;
-        hipError_t e = hipMalloc(reinterpret_cast<void**>(&out->d_cell_start), (n_cells + 1) * sizeof(uint32_t));
-        if (e != hipSuccess) { fail(e, "hipMalloc(direction cells)"); break; }
+        hipError_t e = hipSuccess;
+        if ((rc = rth::block_alloc(reinterpret_cast<void**>(&out->d_cell_start), (n_cells + 1) * sizeof(uint32_t))) != RT_OK) break;
         if ((e = hipMemsetAsync(out->d_cell_start, 0, (n_cells + 1) * sizeof(uint32_t), nullptr)) != hipSuccess) { fail(e, "hipMemsetAsync"); break; }
         raster_kernel<false><<<n_cands * 6u, 256, 0, nullptr>>>(d_cands, n_cands, res, out->d_cell_start, nullptr);
         // 64-bit total first: the 32-bit offsets are only meaningful when it fits
         unsigned long long* d_total = nullptr;
         size_t temp_bytes = 0;
-        if ((e = hipMalloc(reinterpret_cast<void**>(&d_total), sizeof(unsigned long long))) != hipSuccess) { fail(e, "hipMalloc"); break; }
+        if ((rc = rth::block_alloc(reinterpret_cast<void**>(&d_total), sizeof(unsigned long long))) != RT_OK) break;
         // (sum of 32-bit counts into a 64-bit total: a transform iterator keeps the reduction from wrapping)
         hipcub::TransformInputIterator<unsigned long long, hipcub::CastOp<unsigned long long>, uint32_t*> wide(out->d_cell_start, hipcub::CastOp<unsigned long long>());
         size_t scan_bytes = 0;
         if ((e = hipcub::DeviceReduce::Sum(nullptr, temp_bytes, wide, d_total, (int)n_cells, nullptr)) != hipSuccess ||
             (e = hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, out->d_cell_start, out->d_cell_start, (int)(n_cells + 1), nullptr)) != hipSuccess) {
-            (void)hipFree(d_total);
+            rth::block_free(d_total);
             fail(e, "hipcub (sizes)");
             break;
         }
         if (scan_bytes > temp_bytes) temp_bytes = scan_bytes;
-        if ((e = hipMalloc(&d_temp, temp_bytes ? temp_bytes : 16)) != hipSuccess) { (void)hipFree(d_total); fail(e, "hipMalloc(scan space)"); break; }
+        if ((rc = rth::block_alloc(&d_temp, temp_bytes ? temp_bytes : 16)) != RT_OK) { rth::block_free(d_total); break; }
         size_t tb = temp_bytes;
         unsigned long long total = 0;
         if ((e = hipcub::DeviceReduce::Sum(d_temp, tb, wide, d_total, (int)n_cells, nullptr)) == hipSuccess)
             e = hipMemcpy(&total, d_total, sizeof total, hipMemcpyDeviceToHost);
-        (void)hipFree(d_total);
+        rth::block_free(d_total);
         if (e != hipSuccess) { fail(e, "hipMemcpy(direction entries total)"); break; }
         if (total > kMaxEntries && res > 16u) {  // start over with cells twice as wide
-            (void)hipFree(d_temp), d_temp = nullptr;
-            (void)hipFree(out->d_cell_start), out->d_cell_start = nullptr;
+            rth::block_free(d_temp), d_temp = nullptr;
+            rth::block_free(out->d_cell_start), out->d_cell_start = nullptr;
             res /= 2u;
             continue;
         }
         if (total >= 0x80000000ull) { rc = RT_ERR_INVALID_SCENE; break; }
         tb = temp_bytes;
         if ((e = hipcub::DeviceScan::ExclusiveSum(d_temp, tb, out->d_cell_start, out->d_cell_start, (int)(n_cells + 1), nullptr)) != hipSuccess) { fail(e, "hipcub::DeviceScan"); break; }
-        if ((e = hipMalloc(reinterpret_cast<void**>(&out->d_entries), (total ? total : 1) * sizeof(uint32_t))) != hipSuccess) { fail(e, "hipMalloc(direction entries)"); break; }
-        if ((e = hipMalloc(reinterpret_cast<void**>(&d_cursor), n_cells * sizeof(uint32_t))) != hipSuccess) { fail(e, "hipMalloc(cursors)"); break; }
+        if ((rc = rth::block_alloc(reinterpret_cast<void**>(&out->d_entries), (total ? total : 1) * sizeof(uint32_t))) != RT_OK) break;
+        if ((rc = rth::block_alloc(reinterpret_cast<void**>(&d_cursor), n_cells * sizeof(uint32_t))) != RT_OK) break;
         if ((e = hipMemcpyAsync(d_cursor, out->d_cell_start, n_cells * sizeof(uint32_t), hipMemcpyDeviceToDevice, nullptr)) != hipSuccess) { fail(e, "hipMemcpyAsync"); break; }
         raster_kernel<true><<<n_cands * 6u, 256, 0, nullptr>>>(d_cands, n_cands, res, d_cursor, out->d_entries);
         sort_cells_kernel<<<(unsigned)((n_cells + 255) / 256), 256, 0, nullptr>>>(out->d_cell_start, (uint32_t)n_cells, out->d_entries);
@@ -220,8 +220,9 @@ int rth::dir_index_build(const RtDirCand* d_cands, uint32_t n_cands, uint32_t re
         out->n_entries = (uint32_t)total;
         break;
     }
-    if (d_cursor) (void)hipFree(d_cursor);
-    if (d_temp) (void)hipFree(d_temp);
+    if (rc != RT_OK) (void)hipStreamSynchronize(nullptr);  // (the blocks below go back to a cache, not to the driver: nothing may still use them)
+    if (d_cursor) rth::block_free(d_cursor);
+    if (d_temp) rth::block_free(d_temp);
     if (rc != RT_OK) dir_index_free(out);
     return rc;
 }

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -598,9 +599,18 @@ const char* rt_hip_last_hip_error(void) { return g_hip_error.c_str(); }
 int rt_hip_scene_create(const RtSceneDesc* desc, RtScene** out) {
     if (!desc || !out) return RT_ERR_INVALID_ARG;
     *out = nullptr;
+    const bool timing = std::getenv("RT_HIP_CREATE_TIMING") != nullptr;  // (studies: where a scene's creation spends its time)
+    auto t_last = std::chrono::steady_clock::now();
+    auto stage = [&](const char* what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "scene_create: %-34s %.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     uint32_t flags = 0;
     const int v = validate(*desc, &flags);
     if (v != RT_OK) return v;
+    stage("validate");
     {
         std::lock_guard<std::mutex> lock(g_mutex);
         const int rc = ensure_device();
@@ -625,6 +635,12 @@ int rt_hip_scene_create(const RtSceneDesc* desc, RtScene** out) {
     // block, filled by one host-to-device copy (the block comes from the library's cache: the drop-in pattern of a
     // scene per frame does not reach the driver's allocator after its first frame).
     rth::Arena arena;
+    // (one allocation for the lot: the tables, as much again at most for the LDS image, the 4-wide hierarchy and leaf records)
+    arena.host.reserve(2 * (sizeof(RtShape) * desc->n_shapes + sizeof(RtConic) * desc->n_conics + sizeof(RtTriangle) * desc->n_triangles +
+                            sizeof(RtGroup) * desc->n_groups + sizeof(RtCsg) * desc->n_csgs + desc->n_lhit + sizeof(RtMaterial) * desc->n_materials +
+                            sizeof(RtPattern) * desc->n_patterns + sizeof(RtBvhNode) * desc->n_bvh_nodes) +
+                       sizeof(RtDirCand) * desc->n_dir_cands + sizeof(uint32_t) * ((size_t)desc->n_dir_entries + 6u * desc->dir_res * desc->dir_res) +
+                       (size_t)desc->n_shapes * 160u + 65536u);
     int rc = RT_OK;
     const size_t o_shapes = arena.add(desc->shapes, sizeof(RtShape) * desc->n_shapes);
     {  // RT_FLAG_IDENTITY: primitives whose inverse transform is the identity matrix bit for bit (rt_trace.h: identity_ray)
@@ -720,7 +736,9 @@ int rt_hip_scene_create(const RtSceneDesc* desc, RtScene** out) {
             }
         }
     }
+    stage("tables into the arena");
     rc = rth::wf2_create(*desc, flags, arena, &s->wf2);
+    stage("4-wide hierarchy, leaf records");
     if (rc != RT_OK) {
         rt_hip_scene_destroy(s);
         return rc;
@@ -760,6 +778,7 @@ int rt_hip_scene_create(const RtSceneDesc* desc, RtScene** out) {
         const hipError_t e = hipMemcpy(base, arena.host.data(), arena.host.size(), hipMemcpyHostToDevice);
         if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy(scene tables)");
     }
+    stage("device block and upload");
     if (rc == RT_OK && cells_here) {  // candidates only: the cells are built here, on the device (rt_dirindex.hip)
         rth::DirIndex ix;
         rc = rth::dir_index_build(s->dev.dir_cands, desc->n_dir_cands, desc->dir_res, &ix);
@@ -775,6 +794,7 @@ int rt_hip_scene_create(const RtSceneDesc* desc, RtScene** out) {
         rt_hip_scene_destroy(s);
         return rc;
     }
+    stage("direction index");
     *out = s;
     return RT_OK;
 }
@@ -783,7 +803,7 @@ void rt_hip_scene_destroy(RtScene* scene) {
     if (!scene) return;
     DeviceGuard device_guard(scene->device);
     (void)hipDeviceSynchronize();  // nothing of this scene's may still be running when its blocks are handed on
-    for (void* p : scene->allocations) (void)hipFree(p);
+    for (void* p : scene->allocations) rth::block_free(p);
     rth::block_free(scene->tables);
     rth::block_free(scene->d_frame);
     for (hipEvent_t e : scene->band_done)

@@ -31,7 +31,7 @@ size_t g_cached_bytes = 0;
 // per process; past that the oldest idle blocks go back to the driver.  Sized for the device: twice the kernel pipeline's
 // largest workspace (rt_wf2.hip, RT_WF2_BUDGET_MB = 24 GiB of the 288) -- a block of more than half the limit is never kept.
 constexpr size_t kMaxCachedBytes = (size_t)48 << 30;
-constexpr size_t kMaxCachedBlocks = 16;
+constexpr size_t kMaxCachedBlocks = 32;
 
 void evict_locked(size_t keep_bytes, size_t keep_blocks) {
     while (!g_free_blocks.empty() && (g_cached_bytes > keep_bytes || g_free_blocks.size() > keep_blocks)) {

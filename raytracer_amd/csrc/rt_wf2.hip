@@ -5,7 +5,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <mutex>
+#include <thread>
 
 #include "rt_host_internal.h"
 #include "rt_wf2.h"
@@ -237,8 +239,12 @@ LeafPre leaf_pre_of(const RtSceneDesc& d, uint32_t shape, double extent) {
     if (!(rho <= 64.0)) return out;
     // compose, innermost last: p_obj = inv_prim * (inv_parent * (... * (inv_outermost * p)))
     double C[3][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}};
-    std::vector<int32_t> chain;
-    for (int32_t p = sh.parent; p >= 0; p = d.shapes[p].parent) chain.push_back(p);
+    int32_t chain[64];  // (validate() holds the nesting far below this)
+    size_t n_chain = 0;
+    for (int32_t p = sh.parent; p >= 0; p = d.shapes[p].parent) {
+        if (n_chain == 64) return out;
+        chain[n_chain++] = p;
+    }
     auto apply = [&](const double* m) {  // C = M * C
         double r[3][4];
         for (int i = 0; i < 3; ++i)
@@ -249,7 +255,7 @@ LeafPre leaf_pre_of(const RtSceneDesc& d, uint32_t shape, double extent) {
             }
         std::memcpy(C, r, sizeof r);
     };
-    for (size_t q = chain.size(); q-- > 0;) apply(d.shapes[chain[q]].inv);
+    for (size_t q = n_chain; q-- > 0;) apply(d.shapes[chain[q]].inv);
     apply(sh.inv);
     // norms of the linear part and of its inverse
     const double a = C[0][0], b = C[0][1], c = C[0][2], e = C[1][0], f = C[1][1], g = C[1][2], h = C[2][0], i2 = C[2][1], j2 = C[2][2];
@@ -422,9 +428,18 @@ int rth::wf2_create(const RtSceneDesc& d, uint32_t scene_flags, Arena& arena, Wf
     // node and no shadowless primitive anywhere (those need the sorted world list per ray: the older kernels have it).
     if (d.world_bvh_root < 0 || (scene_flags & RT_SCENE_HAS_SHADOWLESS) || d.n_csgs != 0 || d.n_lights == 0) return RT_OK;
     if (d.n_shapes >= (1u << RT_BVH4_SHAPE_BITS)) return RT_OK;  // (a leaf code's upper bits: flags, and the owner lane in the leaf exchange)
+    const bool timing = std::getenv("RT_HIP_CREATE_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto stage = [&](const char* what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "  wf2_create: %-32s %.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     std::vector<TNode> tree;
     std::vector<uint32_t> top;
     if (!parse_seq(d, d.world_bvh_root, -1, tree, top, 0) || top.empty()) return RT_OK;
+    stage("skip links -> tree");
     for (const TNode& t : tree)
         if (t.shape >= 0 && RT_KIND(d.shapes[t.shape].kind_flags) > RT_SMOOTH_TRIANGLE) return RT_OK;
     Wf2* w = new Wf2();
@@ -458,6 +473,7 @@ int rth::wf2_create(const RtSceneDesc& d, uint32_t scene_flags, Arena& arena, Wf
         w->accel.root = b.emit(top, need);
         w->stack_need = need + 1u;  // + the sentinel
     }
+    stage("4-wide nodes");
     {  // the hierarchy over the open primitives (see WF2_CONTAINERS in rt_wf2.h)
         auto open = [&](int32_t shape) {
             const RtShape& sh = d.shapes[shape];
@@ -485,6 +501,7 @@ int rth::wf2_create(const RtSceneDesc& d, uint32_t scene_flags, Arena& arena, Wf
             w->stack_need = std::max(w->stack_need, need + 1u);
         }
     }
+    stage("open primitives' hierarchy");
     w->stack_need += w->accel.n_always;
     if (w->stack_need > RT_WF2_MAX_STACK || !b.ok) {
         delete w;
@@ -500,17 +517,38 @@ int rth::wf2_create(const RtSceneDesc& d, uint32_t scene_flags, Arena& arena, Wf
     w->accel.extent_max = std::fmax(w->accel.extent[0], std::fmax(w->accel.extent[1], w->accel.extent[2]));
     std::vector<LeafPre> pre(d.n_shapes);
     for (LeafPre& p : pre) std::memset(&p, 0, sizeof p), p.kind = RT_PRE_NONE, p.anc[0] = RT_PRE_DEEP, p.anc[1] = RT_PRE_NO_ANC;
-    for (const TNode& t : tree)
-        if (t.shape >= 0) {
-            LeafPre& p = pre[(size_t)t.shape];
-            p = leaf_pre_of(d, (uint32_t)t.shape, w->accel.extent_max);
-            // the enclosing groups, outermost first, when there are at most two
-            std::vector<int32_t> chain;
-            for (int32_t a = d.shapes[t.shape].parent; a >= 0; a = d.shapes[a].parent) chain.push_back(a);
-            p.anc[0] = p.anc[1] = RT_PRE_NO_ANC;
-            if (chain.size() > 2) p.anc[0] = RT_PRE_DEEP;
-            else for (size_t k = 0; k < chain.size(); ++k) p.anc[k] = (uint32_t)chain[chain.size() - 1 - k];
+    {  // one record per leaf, each on its own: on a few host threads when there are many
+        std::vector<int32_t> leaf_shapes;
+        leaf_shapes.reserve(tree.size() / 2 + 1);
+        for (const TNode& t : tree)
+            if (t.shape >= 0) leaf_shapes.push_back(t.shape);
+        const double extent_max = w->accel.extent_max;
+        auto work = [&](size_t k0, size_t k1) {
+            for (size_t k = k0; k < k1; ++k) {
+                const int32_t shape = leaf_shapes[k];
+                LeafPre& p = pre[(size_t)shape];
+                p = leaf_pre_of(d, (uint32_t)shape, extent_max);
+                // the enclosing groups, outermost first, when there are at most two
+                int32_t chain[3];
+                size_t n_chain = 0;
+                for (int32_t a = d.shapes[shape].parent; a >= 0 && n_chain < 3; a = d.shapes[a].parent) chain[n_chain++] = a;
+                p.anc[0] = p.anc[1] = RT_PRE_NO_ANC;
+                if (n_chain > 2) p.anc[0] = RT_PRE_DEEP;
+                else for (size_t q = 0; q < n_chain; ++q) p.anc[q] = (uint32_t)chain[n_chain - 1 - q];
+            }
+        };
+        unsigned n_threads = leaf_shapes.size() >= 4096 ? std::min(4u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+        if (n_threads <= 1u) {
+            work(0, leaf_shapes.size());
+        } else {
+            std::vector<std::thread> pool;
+            for (unsigned t = 1; t < n_threads; ++t)
+                pool.emplace_back(work, leaf_shapes.size() * t / n_threads, leaf_shapes.size() * (t + 1) / n_threads);
+            work(0, leaf_shapes.size() / n_threads);
+            for (std::thread& th : pool) th.join();
         }
+    }
+    stage("leaf records");
     {  // leaves without a pre-test say so in their code (the walk then reads two of the record's five words)
         auto flag = [&](uint32_t code) {
             if ((code & RT_BVH4_LEAF) && code != RT_BVH4_DONE) {
@@ -596,7 +634,9 @@ int rth::wf2_create(const RtSceneDesc& d, uint32_t scene_flags, Arena& arena, Wf
         }
         return RT_OK;
     };
+    stage("into the arena");
     const int rc = body();
+    stage("occupancy, stream, events");
     if (rc != RT_OK) {
         rth::wf2_destroy(w);
         return rc;

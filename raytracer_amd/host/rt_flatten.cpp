@@ -266,7 +266,7 @@ void build_bvh_range(std::vector<BvhItem>& items, size_t lo, size_t hi, int32_t 
     const size_t n_left = best_mid - lo;
     const size_t right_self = self + 1 + (2 * n_left - 1);
     const int32_t right_root = static_cast<int32_t>(right_self);
-    if (par_depth > 0 && n >= 2048) {
+    if (par_depth > 0 && n >= 512) {
         std::thread left([&] { build_bvh_range(items, lo, best_mid, right_root, nodes, self + 1, par_depth - 1); });
         build_bvh_range(items, best_mid, hi, after, nodes, right_self, par_depth - 1);
         left.join();
@@ -291,7 +291,7 @@ int32_t build_bvh(std::vector<BvhItem> items, std::vector<RtBvhNode>& nodes) {
     if (!bounded.empty()) {
         nodes.resize(nodes.size() + tree_nodes);
         unsigned hw = std::thread::hardware_concurrency();
-        int par_depth = hw >= 8 ? 3 : (hw >= 4 ? 2 : (hw >= 2 ? 1 : 0));
+        int par_depth = hw >= 16 ? 4 : (hw >= 8 ? 3 : (hw >= 4 ? 2 : (hw >= 2 ? 1 : 0)));
         if (const char* e = std::getenv("RT_FLATTEN_THREADS")) par_depth = std::atoi(e) <= 1 ? 0 : par_depth;  // study knob
         build_bvh_range(bounded, 0, bounded.size(), unbounded.empty() ? -1 : first_unbounded, nodes.data(), static_cast<size_t>(root), par_depth);
     }
