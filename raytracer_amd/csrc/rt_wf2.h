@@ -1490,9 +1490,10 @@ RT_DEV unsigned wf2_sort_key(const WfItem& it, float ex, float ey, float ez) {
     }
     return key;
 }
-// (Round 3: 1024 threads per slice instead of 256 -- one block per compute unit wants every wave slot it can get --, each
-// item's key kept in LDS between the counting pass and the moving pass, the 512 counters scanned by one wave instead of one
-// lane, and an item moved by four lanes, 16 bytes each, so that a wave's loads and stores cover whole 64-byte items.)
+// (Round 3: 1024 threads per slice instead of 256 -- one block per compute unit wants every wave slot it can get --, an item
+// read and moved by four lanes, 16 bytes each, so that a wave's loads and stores cover whole 64-byte items; each of the four
+// works out the part of the key its piece holds and the quad ORs the parts together; the 512 counters scanned by one wave
+// instead of one lane.)
 #ifndef RT_WF2_COMPACT_THREADS
 #ifdef RT_HOST_EMU
 #define RT_WF2_COMPACT_THREADS 256u
@@ -1500,25 +1501,64 @@ RT_DEV unsigned wf2_sort_key(const WfItem& it, float ex, float ey, float ez) {
 #define RT_WF2_COMPACT_THREADS 1024u
 #endif
 #endif
-#define RT_WF2_COMPACT_KEYS 24576u  // items of a slice whose keys are remembered (the others work theirs out again)
+#ifndef RT_WF2_COMPACT_SYNC
+#define RT_WF2_COMPACT_SYNC 1
+#endif
+// the part of wf2_sort_key() that piece `piece` (16 bytes) of an item decides: ray.o.x, o.y | o.z, d.x | d.y, d.z | the rest
+RT_DEV unsigned wf2_sort_key_part(unsigned piece, const uint4& v, float ex, float ey, float ez) {
+    static_assert(RT_WF_BINS == 8u, "the key's parts OR together only with plain octants");
+    const double a = __longlong_as_double((long long)(((unsigned long long)v.y << 32) | v.x));
+    const double b = __longlong_as_double((long long)(((unsigned long long)v.w << 32) | v.z));
+    const float n = (float)RT_WF2_SORT_CELLS;
+    auto cell = [n](double o, float e) {
+        const float u = ((float)o / e + 1.f) * 0.5f * n;
+        return (unsigned)(u > 0.f ? (u < n ? u : n - 1.f) : 0.f);  // (NaN -> 0)
+    };
+    auto spread = [](unsigned c, unsigned axis) {
+        unsigned m = 0;
+#pragma unroll
+        for (unsigned bit = 0; (1u << bit) < RT_WF2_SORT_CELLS; ++bit) m |= ((c >> bit) & 1u) << (3u * bit + axis);
+        return m;
+    };
+    unsigned key = 0;
+    if (piece == 0u) {
+        if constexpr (RT_WF2_SORT_CELLS > 1u) key = (spread(cell(a, ex), 0u) | spread(cell(b, ey), 1u)) * RT_WF_BINS;
+    } else if (piece == 1u) {
+        if constexpr (RT_WF2_SORT_CELLS > 1u) key = spread(cell(a, ez), 2u) * RT_WF_BINS;
+        key |= b < 0.0 ? 1u : 0u;
+    } else if (piece == 2u) {
+        key = (a < 0.0 ? 2u : 0u) | (b < 0.0 ? 4u : 0u);
+    }
+    return key;
+}
 __global__ __launch_bounds__(RT_WF2_COMPACT_THREADS) void wf2_compact_kernel(Wf2Space sp, unsigned gen, float ex, float ey, float ez) {
     constexpr unsigned KEYS = RT_WF_BINS * RT_WF2_SORT_CELLS * RT_WF2_SORT_CELLS * RT_WF2_SORT_CELLS;
     constexpr unsigned PER = (KEYS + 63u) / 64u;  // counters per lane of the scanning wave
-    static_assert(KEYS <= 65536u, "keys are kept as 16-bit values");
-    static_assert(sizeof(WfItem) == 64, "an item is moved as four 16-byte pieces");
+    static_assert(sizeof(WfItem) == 64 && offsetof(WfItem, ray) == 0, "an item is four 16-byte pieces, the ray first");
     __shared__ unsigned count[KEYS];
-    __shared__ unsigned short keys[RT_WF2_COMPACT_KEYS];
     const unsigned nt = blockDim.x, tid = threadIdx.x;
     const unsigned shard = blockIdx.x;
     const unsigned begin = sp.cnt->offsets[shard], n = sp.cnt->offsets[shard + 1u] - begin;
-    const WfItem* __restrict__ src = sp.ws.queue[(gen + 1u) & 1u] + (size_t)shard * sp.ws.q_cap;
-    WfItem* __restrict__ dst = sp.qd + begin;
+    const uint4* __restrict__ src4 = reinterpret_cast<const uint4*>(sp.ws.queue[(gen + 1u) & 1u] + (size_t)shard * sp.ws.q_cap);
+    uint4* __restrict__ dst4 = reinterpret_cast<uint4*>(sp.qd + begin);
+    const unsigned piece = tid & 3u;
+    const unsigned n_round = (n + 15u) & ~15u;  // (whole waves reach the shuffles below)
+    // the key of the quad's item, in all four lanes
+    auto quad_key = [&](unsigned part) {
+        part |= (unsigned)__shfl_xor((int)part, 1, 64);
+        part |= (unsigned)__shfl_xor((int)part, 2, 64);
+        return part;
+    };
     for (unsigned k = tid; k < KEYS; k += nt) count[k] = 0u;
     __syncthreads();
-    for (unsigned i = tid; i < n; i += nt) {
-        const unsigned key = wf2_sort_key(src[i], ex, ey, ez);
-        if (i < RT_WF2_COMPACT_KEYS) keys[i] = (unsigned short)key;
-        atomicAdd(&count[key], 1u);
+    for (unsigned i = tid >> 2; i < n_round; i += nt >> 2) {
+        uint4 v = {0u, 0u, 0u, 0u};
+        if (i < n) v = src4[(size_t)i * 4u + piece];
+        const unsigned key = quad_key(wf2_sort_key_part(piece, v, ex, ey, ez));
+#ifdef RT_HOST_EMU  // (tests/emu: the quad's key is the whole item's key)
+        if (i < n && key != wf2_sort_key(reinterpret_cast<const WfItem*>(src4)[i], ex, ey, ez)) std::abort();
+#endif
+        if (i < n && piece == 0u) atomicAdd(&count[key], 1u);
     }
     __syncthreads();
     if (tid < 64u) {  // counts -> where each key's run starts
@@ -1544,22 +1584,17 @@ __global__ __launch_bounds__(RT_WF2_COMPACT_THREADS) void wf2_compact_kernel(Wf2
         }
     }
     __syncthreads();
-    const uint4* __restrict__ src4 = reinterpret_cast<const uint4*>(src);
-    uint4* __restrict__ dst4 = reinterpret_cast<uint4*>(dst);
-    const unsigned piece = tid & 3u;
-    const unsigned n_round = (n + 15u) & ~15u;  // (whole waves reach the shuffle below)
     for (unsigned i = tid >> 2; i < n_round; i += nt >> 2) {
-        unsigned to = 0u;
         uint4 v = {0u, 0u, 0u, 0u};
-        if (i < n) {
-            v = src4[(size_t)i * 4u + piece];
-            if (piece == 0u) {
-                const unsigned key = i < RT_WF2_COMPACT_KEYS ? (unsigned)keys[i] : wf2_sort_key(src[i], ex, ey, ez);
-                to = atomicAdd(&count[key], 1u);
-            }
-        }
+        if (i < n) v = src4[(size_t)i * 4u + piece];
+        const unsigned key = quad_key(wf2_sort_key_part(piece, v, ex, ey, ez));
+        unsigned to = 0u;
+        if (i < n && piece == 0u) to = atomicAdd(&count[key], 1u);
         to = (unsigned)__shfl((int)to, (int)((tid & 63u) & ~3u), 64);
         if (i < n) dst4[(size_t)to * 4u + piece] = v;
+#if RT_WF2_COMPACT_SYNC
+        __syncthreads();  // the block's waves stay within one stretch of the slice: a key's run keeps the slice's order to within it
+#endif
     }
 }
 

@@ -111,6 +111,10 @@ template <class T> inline T shfl_down(T v, unsigned off) {
     const unsigned long long* b = wave->exchange(lane(), pack(v), kShflDown);
     return lane() + off < 64u ? unpack<T>(b[lane() + off]) : v;
 }
+template <class T> inline T shfl_xor(T v, unsigned mask) {
+    if (!wave) { if (mask != 0u) std::abort(); return v; }
+    return unpack<T>(wave->exchange(lane(), pack(v), kShfl)[(lane() ^ mask) & 63u]);
+}
 template <class T> inline T first_lane(T v) { return wave ? unpack<T>(wave->exchange(lane(), pack(v), kFirstLane)[0]) : v; }
 inline void wave_barrier() { if (wave) (void)wave->exchange(lane(), 0ull, kWaveBarrier); }
 inline void block_barrier() { if (block) (void)block->exchange(threadIdx.x, 0ull, kSyncThreads); }
@@ -124,6 +128,7 @@ inline void block_barrier() { if (block) (void)block->exchange(threadIdx.x, 0ull
 inline unsigned __lane_id() { return hip_emu::lane(); }
 inline void __syncthreads() { hip_emu::block_barrier(); }
 template <class T> inline T __shfl(T v, int src, int = 64) { return hip_emu::shfl(v, src); }
+template <class T> inline T __shfl_xor(T v, int mask, int = 64) { return hip_emu::shfl_xor(v, (unsigned)mask); }
 template <class T> inline T __shfl_down(T v, unsigned off, int = 64) { return hip_emu::shfl_down(v, off); }
 template <class T> inline T __shfl_up(T v, unsigned off, int = 64) { return hip_emu::shfl_up(v, off); }
 inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
