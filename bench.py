@@ -307,7 +307,8 @@ def main():
                               "frac": round(achieved_f32 / flops.PEAK_FP32_VALU_TFLOPS, 5)},
                 "frac_combined_r02": round((achieved + achieved_f32) / flops.PEAK_FP64_VALU_TFLOPS, 5),
                 "kernel_ms": round(kernel_ms, 4),
-                "traffic": measured_traffic(args, n_parts),
+                "traffic": measured_traffic(args, n_parts)[0],
+                "traffic_source": measured_traffic(args, n_parts)[1],
             },
         }
         if n_parts == 1 and not args.no_cpu_baseline:
@@ -323,9 +324,13 @@ def measured_traffic(args, n_parts):
     counters cannot be read from inside the process), or None when this configuration was not profiled."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            return json.load(f).get(f"{args.workload}:{args.width}x{args.height}:{n_parts}")
+            table = json.load(f)
+        key = f"{args.workload}:{args.width}x{args.height}:{n_parts}"
+        if args.depth != 5 or args.wavefront not in (-1, 2) or (args.workload == "synthetic" and args.primitives != 10000):
+            return None, None  # (not the command the counters were taken on)
+        return table.get(key), table.get("_source", {}).get(key)
     except OSError:
-        return None
+        return None, None
 
 
 def _time_oracle(ow, cam, threads, seconds):
