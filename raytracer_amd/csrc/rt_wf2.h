@@ -1490,10 +1490,15 @@ RT_DEV unsigned wf2_sort_key(const WfItem& it, float ex, float ey, float ez) {
     }
     return key;
 }
-// (Round 3: 1024 threads per slice instead of 256 -- one block per compute unit wants every wave slot it can get --, an item
-// read and moved by four lanes, 16 bytes each, so that a wave's loads and stores cover whole 64-byte items; each of the four
-// works out the part of the key its piece holds and the quad ORs the parts together; the 512 counters scanned by one wave
-// instead of one lane.)
+// (Round 3.)  A STABLE counting sort, 1024 threads per slice: the order of a slice is the order its hits were in, rays that
+// were neighbours there walk the same part of the hierarchy, and every kernel of the next generation works in the dense
+// queue's order (slot = ray index) -- measured: with places handed out by plain atomics, in whatever order sixteen waves
+// arrive, the next generation's walks are 8 % longer than with the slice's order kept.  So: wave w of the block owns the
+// w-th sixteenth of the slice; the first pass counts per (key, wave); ONE exclusive scan over the counters laid out key-major,
+// wave-minor turns each into the place of the first item of that key in that wave's part; the second pass goes through the
+// wave's part in order, 16 items a step, ranks the items of equal key among themselves (lane order), and the first of each
+// key takes the places for all of them from the wave's OWN counter -- no wave waits for another.  An item is read and moved
+// by four lanes, 16 bytes each (whole 64-byte items per instruction), which OR their parts of the key together.
 #ifndef RT_WF2_COMPACT_THREADS
 #ifdef RT_HOST_EMU
 #define RT_WF2_COMPACT_THREADS 256u
@@ -1501,8 +1506,8 @@ RT_DEV unsigned wf2_sort_key(const WfItem& it, float ex, float ey, float ez) {
 #define RT_WF2_COMPACT_THREADS 1024u
 #endif
 #endif
-#ifndef RT_WF2_COMPACT_SYNC
-#define RT_WF2_COMPACT_SYNC 1
+#ifndef RT_WF2_COMPACT_AHEAD
+#define RT_WF2_COMPACT_AHEAD 4u  // steps of 16 items whose loads a wave has in flight together
 #endif
 // the part of wf2_sort_key() that piece `piece` (16 bytes) of an item decides: ray.o.x, o.y | o.z, d.x | d.y, d.z | the rest
 RT_DEV unsigned wf2_sort_key_part(unsigned piece, const uint4& v, float ex, float ey, float ez) {
@@ -1533,69 +1538,117 @@ RT_DEV unsigned wf2_sort_key_part(unsigned piece, const uint4& v, float ex, floa
 }
 __global__ __launch_bounds__(RT_WF2_COMPACT_THREADS) void wf2_compact_kernel(Wf2Space sp, unsigned gen, float ex, float ey, float ez) {
     constexpr unsigned KEYS = RT_WF_BINS * RT_WF2_SORT_CELLS * RT_WF2_SORT_CELLS * RT_WF2_SORT_CELLS;
-    constexpr unsigned PER = (KEYS + 63u) / 64u;  // counters per lane of the scanning wave
+    constexpr unsigned NW = RT_WF2_COMPACT_THREADS / 64u;          // waves of the block
+    constexpr unsigned CELLS = KEYS * NW;                          // counters, [key][wave]
+    constexpr unsigned PER = CELLS / RT_WF2_COMPACT_THREADS;       // counters per thread in the scan
+    constexpr unsigned AHEAD = RT_WF2_COMPACT_AHEAD;
+    static_assert(CELLS % RT_WF2_COMPACT_THREADS == 0u && CELLS * 4u <= 48u * 1024u, "the counters: a whole number per thread, in LDS");
     static_assert(sizeof(WfItem) == 64 && offsetof(WfItem, ray) == 0, "an item is four 16-byte pieces, the ray first");
-    __shared__ unsigned count[KEYS];
-    const unsigned nt = blockDim.x, tid = threadIdx.x;
+    __shared__ unsigned cells[CELLS];
+    __shared__ unsigned wave_sum[NW];
+    const unsigned tid = threadIdx.x;  // (blockDim.x == RT_WF2_COMPACT_THREADS: the one launch site says so)
     const unsigned shard = blockIdx.x;
     const unsigned begin = sp.cnt->offsets[shard], n = sp.cnt->offsets[shard + 1u] - begin;
+    if (n == 0u) return;  // (the whole block: nothing in this slice)
     const uint4* __restrict__ src4 = reinterpret_cast<const uint4*>(sp.ws.queue[(gen + 1u) & 1u] + (size_t)shard * sp.ws.q_cap);
     uint4* __restrict__ dst4 = reinterpret_cast<uint4*>(sp.qd + begin);
-    const unsigned piece = tid & 3u;
-    const unsigned n_round = (n + 15u) & ~15u;  // (whole waves reach the shuffles below)
+    const unsigned piece = tid & 3u, lane = tid & 63u, quad = lane >> 2, wave = tid >> 6;
+    // the wave's part of the slice: whole steps of 16 items
+    const unsigned part = ((n + NW - 1u) / NW + 15u) & ~15u;
+    const unsigned lo = wave * part < n ? wave * part : n, hi = lo + part < n ? lo + part : n;
     // the key of the quad's item, in all four lanes
-    auto quad_key = [&](unsigned part) {
-        part |= (unsigned)__shfl_xor((int)part, 1, 64);
-        part |= (unsigned)__shfl_xor((int)part, 2, 64);
-        return part;
+    auto quad_key = [&](unsigned p) {
+        p |= (unsigned)__shfl_xor((int)p, 1, 64);
+        p |= (unsigned)__shfl_xor((int)p, 2, 64);
+        return p;
     };
-    for (unsigned k = tid; k < KEYS; k += nt) count[k] = 0u;
+    for (unsigned k = tid; k < CELLS; k += RT_WF2_COMPACT_THREADS) cells[k] = 0u;
     __syncthreads();
-    for (unsigned i = tid >> 2; i < n_round; i += nt >> 2) {
-        uint4 v = {0u, 0u, 0u, 0u};
-        if (i < n) v = src4[(size_t)i * 4u + piece];
-        const unsigned key = quad_key(wf2_sort_key_part(piece, v, ex, ey, ez));
+    for (unsigned base = lo; base < hi; base += AHEAD * 16u) {  // (wave-uniform bounds: whole waves reach the shuffles)
+        uint4 v[AHEAD];
+#pragma unroll
+        for (unsigned u = 0; u < AHEAD; ++u) {
+            const unsigned i = base + u * 16u + quad;
+            v[u] = uint4{0u, 0u, 0u, 0u};
+            if (i < hi) v[u] = src4[(size_t)i * 4u + piece];
+        }
+#pragma unroll
+        for (unsigned u = 0; u < AHEAD; ++u) {
+            const unsigned i = base + u * 16u + quad;
+            const unsigned key = quad_key(wf2_sort_key_part(piece, v[u], ex, ey, ez));
 #ifdef RT_HOST_EMU  // (tests/emu: the quad's key is the whole item's key)
-        if (i < n && key != wf2_sort_key(reinterpret_cast<const WfItem*>(src4)[i], ex, ey, ez)) std::abort();
+            if (i < hi && key != wf2_sort_key(reinterpret_cast<const WfItem*>(src4)[i], ex, ey, ez)) std::abort();
 #endif
-        if (i < n && piece == 0u) atomicAdd(&count[key], 1u);
+            if (i < hi && piece == 0u) atomicAdd(&cells[key * NW + wave], 1u);
+        }
     }
     __syncthreads();
-    if (tid < 64u) {  // counts -> where each key's run starts
+    {  // exclusive scan of the counters as laid out: thread t's PER consecutive ones, the wave's threads, the block's waves
         unsigned mine[PER], sum = 0u;
 #pragma unroll
         for (unsigned j = 0; j < PER; ++j) {
-            const unsigned k = tid * PER + j;
-            mine[j] = k < KEYS ? count[k] : 0u;
+            mine[j] = cells[tid * PER + j];
             sum += mine[j];
         }
         unsigned incl = sum;
 #pragma unroll
         for (unsigned off = 1u; off < 64u; off <<= 1) {
             const unsigned up = __shfl_up(incl, off, 64);
-            if (tid >= off) incl += up;
+            if (lane >= off) incl += up;
         }
+        if (lane == 63u) wave_sum[wave] = incl;
+        __syncthreads();
         unsigned run = incl - sum;
+        for (unsigned w = 0; w < wave; ++w) run += wave_sum[w];
 #pragma unroll
         for (unsigned j = 0; j < PER; ++j) {
-            const unsigned k = tid * PER + j;
-            if (k < KEYS) count[k] = run;
+            cells[tid * PER + j] = run;
             run += mine[j];
         }
     }
     __syncthreads();
-    for (unsigned i = tid >> 2; i < n_round; i += nt >> 2) {
-        uint4 v = {0u, 0u, 0u, 0u};
-        if (i < n) v = src4[(size_t)i * 4u + piece];
-        const unsigned key = quad_key(wf2_sort_key_part(piece, v, ex, ey, ez));
-        unsigned to = 0u;
-        if (i < n && piece == 0u) to = atomicAdd(&count[key], 1u);
-        to = (unsigned)__shfl((int)to, (int)((tid & 63u) & ~3u), 64);
-        if (i < n) dst4[(size_t)to * 4u + piece] = v;
-#if RT_WF2_COMPACT_SYNC
-        __syncthreads();  // the block's waves stay within one stretch of the slice: a key's run keeps the slice's order to within it
-#endif
+    for (unsigned base = lo; base < hi; base += AHEAD * 16u) {
+        uint4 v[AHEAD];
+#pragma unroll
+        for (unsigned u = 0; u < AHEAD; ++u) {
+            const unsigned i = base + u * 16u + quad;
+            v[u] = uint4{0u, 0u, 0u, 0u};
+            if (i < hi) v[u] = src4[(size_t)i * 4u + piece];
+        }
+#pragma unroll
+        for (unsigned u = 0; u < AHEAD; ++u) {
+            const unsigned i = base + u * 16u + quad;
+            const bool valid = i < hi;
+            const unsigned item_key = quad_key(wf2_sort_key_part(piece, v[u], ex, ey, ez));  // (every lane: a shuffle)
+            const unsigned key = valid ? item_key : 0xffffffffu;
+            unsigned rank = 0u, total = 0u, first_quad = quad;
+#pragma unroll
+            for (unsigned j = 0; j < 16u; ++j) {
+                const unsigned kj = (unsigned)__builtin_amdgcn_readlane((int)key, (int)(j * 4u));
+                const bool same = kj == key;
+                if (same && j < quad) ++rank;
+                if (same && j < first_quad) first_quad = j;
+                if (same) ++total;
+            }
+            unsigned to = 0u;
+            if (valid && piece == 0u && rank == 0u) to = atomicAdd(&cells[key * NW + wave], total);
+            __builtin_amdgcn_wave_barrier();  // (nothing on the device; tests/emu: the next step's atomics come after this one's)
+            to = (unsigned)__shfl((int)to, (int)(first_quad * 4u), 64) + rank;
+            if (valid) dst4[(size_t)to * 4u + piece] = v[u];
+        }
     }
+#ifdef RT_HOST_EMU  // (tests/emu: the dense queue is the slice sorted by key, equal keys in the slice's order)
+    __syncthreads();
+    if (tid == 0u) {
+        const WfItem* src = reinterpret_cast<const WfItem*>(src4);
+        const WfItem* dst = reinterpret_cast<const WfItem*>(dst4);
+        unsigned at = 0u;
+        for (unsigned k = 0; k < KEYS; ++k)
+            for (unsigned i = 0; i < n; ++i)
+                if (wf2_sort_key(src[i], ex, ey, ez) == k && std::memcmp(&dst[at++], &src[i], sizeof(WfItem)) != 0) std::abort();
+        if (at != n) std::abort();
+    }
+#endif
 }
 
 }  // namespace rtk

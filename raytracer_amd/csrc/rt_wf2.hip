@@ -393,7 +393,7 @@ void free_space(Wf2* w) {
 
 // One block from the library's cache of device blocks (rt_hostmem.hip), laid out by carve_space: a scene created, rendered
 // once and destroyed -- what rt_hip_render does per call -- takes the workspace the scene before it gave back instead of
-// fifteen hipMalloc / hipFree pairs (the 8K frame's 17 GB: 450 of the call's 530 ms).
+// fifteen hipMalloc / hipFree pairs (the 8K frame's 21 GB: 450 of the call's 530 ms).
 int ensure_space(Wf2* w, size_t items, size_t q_items, size_t node_items, uint32_t n_lights) {
     if (w->sp.cnt && w->batch_pixels >= items && w->q_items == q_items && w->node_items == node_items) return RT_OK;
     if (w->sp.cnt) {

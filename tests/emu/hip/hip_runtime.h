@@ -124,6 +124,7 @@ inline void block_barrier() { if (block) (void)block->exchange(threadIdx.x, 0ull
 #define __builtin_amdgcn_readlane(x, l) hip_emu::shfl((x), (l))
 #define __builtin_amdgcn_wave_barrier() hip_emu::wave_barrier()
 #define __builtin_amdgcn_fence(...) ((void)0)
+#define __builtin_amdgcn_s_sleep(x) std::this_thread::sleep_for(std::chrono::microseconds(20))
 #define __builtin_amdgcn_s_memtime() 0ull
 inline unsigned __lane_id() { return hip_emu::lane(); }
 inline void __syncthreads() { hip_emu::block_barrier(); }

@@ -25,7 +25,7 @@ def emu():
     return os.path.join(ROOT, "build", "emu", "emu_main")
 
 
-@pytest.mark.parametrize("args", [("synthetic", "40", "24", "1500"), ("csg", "48", "27")])
+@pytest.mark.parametrize("args", [("synthetic", "24", "16", "1500", "quick"), ("csg", "48", "27")])
 def test_kernels_are_clean_under_asan_and_ubsan(emu, args):
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
     r = subprocess.run([emu, *args], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
