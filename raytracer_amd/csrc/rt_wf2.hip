@@ -677,6 +677,21 @@ int run_pipeline(const RtScene* scene, const Wf2* w, const Wf2Space& sp, size_t 
 #else
     const dim3 wide(2048), threads(256), overflow_grid(4096);
 #endif
+    // grids of the grid-stride shading kernels (RT_HIP_WF2_{SPAWN,PREPARE,LIGHT}_BLOCKS: studies).  Measured, 4K / 8K frame of
+    // the 10k scene: spawn at 256 / 512 / 1024 / 2048 / 4096 / 8192 / 16384 blocks 17.00 / 16.68 / 16.55 / 16.43 / 16.35 / 16.35 /
+    // 16.36 ms, 8K 52.9 (512) / 52.0 (2048) / 51.45 (8192); then prepare at 1024 / 2048 / 8192: 16.36 / 16.35 / 16.26, light at 512 /
+    // 1024 / 2048 / 8192: 16.54 / 16.43 / 16.35 / 16.26 (8K: 51.4 -> 51.2 either way)
+    auto blocks_of = [](const char* name, unsigned dflt) {
+        const char* e = std::getenv(name);
+        const long v = e && *e ? std::atol(e) : 0;
+        return dim3(v >= 1 && v <= 65536 ? (unsigned)v : dflt);
+    };
+#ifdef RT_HOST_EMU
+    const dim3 spawn_grid = wide, prepare_grid = wide, light_grid = wide;
+#else
+    const dim3 spawn_grid = blocks_of("RT_HIP_WF2_SPAWN_BLOCKS", 8192u), prepare_grid = blocks_of("RT_HIP_WF2_PREPARE_BLOCKS", 8192u),
+               light_grid = blocks_of("RT_HIP_WF2_LIGHT_BLOCKS", 8192u);
+#endif
     auto go = [&](auto stats_tag) {
         constexpr bool ST = decltype(stats_tag)::value;
         dim3 tgrid[4] = {dim3((unsigned)(w->n_cus * w->trace_blocks_per_cu[ST][0])), dim3((unsigned)(w->n_cus * w->trace_blocks_per_cu[ST][1])),
@@ -715,11 +730,11 @@ int run_pipeline(const RtScene* scene, const Wf2* w, const Wf2Space& sp, size_t 
                         hipLaunchKernelGGL((wf2_packet_kernel<ST, WF2_PRIMARY>), dim3((unsigned)(w->n_cus * w->packet_blocks_per_cu[ST][0])), dim3(64), 0, stream, S, A, spg, *cam, rows, g, d_stats, status);
                     else
                         hipLaunchKernelGGL((wf2_trace_kernel<ST, WF2_PRIMARY>), tgrid[0], dim3(64), 0, stream, S, A, spg, *cam, rows, g, d_stats, status);
-                    hipLaunchKernelGGL((wf2_prepare_kernel<ST, true>), wide, threads, 0, stream, S, A.pre, spg, *cam, rows, (int)depth, g, d_out, d_stats, status);
+                    hipLaunchKernelGGL((wf2_prepare_kernel<ST, true>), prepare_grid, threads, 0, stream, S, A.pre, spg, *cam, rows, (int)depth, g, d_out, d_stats, status);
                 } else {
                     if (cands_pass) hipLaunchKernelGGL((wf2_cands_kernel<ST, WF2_QUEUE>), wide, threads, 0, stream, S, spg, *cam, rows, g, d_stats, status);
                     hipLaunchKernelGGL((wf2_trace_kernel<ST, WF2_QUEUE>), tgrid[1], dim3(64), 0, stream, S, A, spg, *cam, rows, g, d_stats, status);
-                    hipLaunchKernelGGL((wf2_prepare_kernel<ST, false>), wide, threads, 0, stream, S, A.pre, spg, *cam, rows, (int)depth, g, d_out, d_stats, status);
+                    hipLaunchKernelGGL((wf2_prepare_kernel<ST, false>), prepare_grid, threads, 0, stream, S, A.pre, spg, *cam, rows, (int)depth, g, d_out, d_stats, status);
                 }
                 const bool more = g < depth && (S.flags & RT_SCENE_RECURSIVE);  // only hits with recursion budget left can have children
                 if (two) {
@@ -733,13 +748,13 @@ int run_pipeline(const RtScene* scene, const Wf2* w, const Wf2Space& sp, size_t 
                     hipLaunchKernelGGL((wf2_trace_kernel<ST, WF2_SHADOW>), tgrid[2], dim3(64), 0, side, S, A, spg, *cam, rows, g, d_stats, status);
                 if (more) {
                     hipLaunchKernelGGL((wf2_trace_kernel<ST, WF2_CONTAINERS>), tgrid[3], dim3(64), 0, stream, S, A, spg, *cam, rows, g, d_stats, status);
-                    hipLaunchKernelGGL((wf2_spawn_kernel<ST>), wide, threads, 0, stream, S, spg, *cam, rows, g, stretch_shift, w->inlane_below, d_stats, status);
+                    hipLaunchKernelGGL((wf2_spawn_kernel<ST>), spawn_grid, threads, 0, stream, S, spg, *cam, rows, g, stretch_shift, w->inlane_below, d_stats, status);
                     if (two) {
                         (void)hipEventRecord(w->spawned[g], stream);
                         (void)hipStreamWaitEvent(side, w->spawned[g], 0);
                     }
                 }
-                hipLaunchKernelGGL((wf2_light_kernel<ST>), wide, threads, 0, side, S, spg, *cam, rows, g, d_out, d_stats, status);
+                hipLaunchKernelGGL((wf2_light_kernel<ST>), light_grid, threads, 0, side, S, spg, *cam, rows, g, d_out, d_stats, status);
                 if (more) hipLaunchKernelGGL((wf2_overflow_kernel<ST>), overflow_grid, dim3(64), 0, side, S, spg, g, d_out, d_stats, status);
                 if (two) (void)hipEventRecord(w->lit[g], side);
                 if (!more) break;
