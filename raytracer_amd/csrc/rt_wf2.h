@@ -785,8 +785,11 @@ __global__ __launch_bounds__(64, RT_WF2_TRACE_WAVES) void wf2_trace_kernel(const
 #ifndef RT_WF2_PACKET
 #define RT_WF2_PACKET 1  // 0: wf2_trace_kernel for every launch (studies)
 #endif
+#ifndef RT_WF2_PACKET_WAVES
+#define RT_WF2_PACKET_WAVES RT_WF2_TRACE_WAVES  // waves per SIMD the wave walk is compiled for.  Measured 4 / 5 / 6 / 8 (128 / 96 / 80 / 64 VGPRs): 16.17 / 16.16 / 16.31 / 16.74 ms
+#endif
 template <bool STATS, int MODE>
-__global__ __launch_bounds__(64, RT_WF2_TRACE_WAVES) void wf2_packet_kernel(const SceneDev S, const Wf2Accel A, Wf2Space sp, RtCameraDesc cam, RowMap rows,
+__global__ __launch_bounds__(64, RT_WF2_PACKET_WAVES) void wf2_packet_kernel(const SceneDev S, const Wf2Accel A, Wf2Space sp, RtCameraDesc cam, RowMap rows,
                                                         unsigned gen, RtStats* __restrict__ stats, unsigned* __restrict__ status) {
     static_assert(MODE == WF2_PRIMARY || MODE == WF2_SHADOW, "closest hits of camera rays, or feelers");
     constexpr int CLS = RT_CLASS_NESTED_LEAVES;
@@ -858,7 +861,8 @@ __global__ __launch_bounds__(64, RT_WF2_TRACE_WAVES) void wf2_packet_kernel(cons
         RT_STAMP(0)
         // ---- the wave's walk.  (LDS traffic between the lanes of ONE wave needs no fence: a wave's LDS instructions are
         // carried out in the order issued; the wave barriers below only keep the compiler from moving them.)
-        // (Keeping the nearest child in registers instead of pushing and popping it was measured: 0.8 ms slower.)
+        // (Keeping the nearest child in registers instead of pushing and popping it was measured, twice, in two forms: 0.6-0.8 ms
+        // slower -- camera rays 1.48 -> 1.77 ms -- with fewer spilled SGPRs and one LDS round trip less per node; not understood.)
         unsigned sp_top = 0u;  // entries on the wave's stack (the same in every lane)
         {
             const unsigned long long all = __builtin_amdgcn_ballot_w64(alive);
